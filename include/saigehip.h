@@ -1,0 +1,154 @@
+/*
+ * saigehip.h -- C ABI of libsaigehip.so, the MI355X (gfx950) implementation of
+ * the SAIGEgds single-variant association scan.
+ *
+ * Drop-in boundary.  In the reference the R driver seqAssocGLMM_SPA()
+ * (R/assoc_single.r:92-334) reaches native code through three .Call entry
+ * points, the last two ONCE PER VARIANT from SeqArray::seqApply
+ * (R/assoc_single.r:207,218 via .cfunction, R/saige_main.r:22-30):
+ *
+ *   SEXP saige_score_test_init (SEXP model)    src/saige_main.cpp:103-150
+ *   SEXP saige_score_test_bin  (SEXP dosage)   src/saige_main.cpp:437-462
+ *   SEXP saige_score_test_quant(SEXP dosage)   src/saige_main.cpp:413-434
+ *
+ * A per-variant callback cannot feed a GPU, so this ABI keeps the meaning of
+ * those three calls and changes the granularity to BLOCKS of variants:
+ *
+ *   sgx_init        <- saige_score_test_init : model arrays by pointer+length,
+ *                      copied to HBM (the reference borrows R-owned memory)
+ *   sgx_scan_2bit   <- saige_score_test_bin/quant over a block; genotypes are
+ *                      2-bit codes, what seqApply(.useraw=NA) yields as RAW
+ *                      0/1/2/0xFF, packed 4 samples per byte
+ *   sgx_scan_u8     <- the RAWSXP branch of get_ds  (saige_main.cpp:179-182)
+ *   sgx_scan_f64    <- the REALSXP branch of get_ds (saige_main.cpp:173-174)
+ *
+ * Results: one row of 8 doubles per variant,
+ *   [AF.alt, mac, num, beta, SE, pval, p.norm, converged]
+ * exactly the NumericVector(8) of saige_score_test_bin (saige_main.cpp:453-458);
+ * for quantitative traits the reference returns 6 values (:427-430) and columns
+ * 6,7 are NaN here.  A variant rejected by the MAF/MAC/missing filter
+ * (saige_main.cpp:288-292, :197-201; reference returns R_NilValue) gets
+ * valid[j]=0 and a NaN row.
+ *
+ * No R, torch or HIP types appear in the signatures.  All functions return 0 on
+ * success or a negative SGX_E* code; sgx_last_error() gives the message (the R
+ * glue turns it into stop(), as BEGIN_RCPP/END_RCPP does in the reference).
+ */
+#ifndef SAIGEHIP_H
+#define SAIGEHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGX_OK          0
+#define SGX_EINVAL     -1   /* bad argument (length, alignment, NULL)          */
+#define SGX_EHIP       -2   /* HIP runtime error                               */
+#define SGX_ENOMEM     -3   /* allocation failed                               */
+#define SGX_ENODEV     -4   /* no usable gfx950 device                         */
+
+#define SGX_MAX_COEFF  16   /* K = nrow(XV) supported by the compiled kernels  */
+#define SGX_TRAIT_BINARY 0
+#define SGX_TRAIT_QUANT  1
+
+/* 2-bit genotype code (alt-allele dosage, SeqArray "$dosage_alt"); sample i of a
+ * variant row lives in bits 2*(i%4)..2*(i%4)+1 of byte i/4. */
+#define SGX_GENO_MISSING 3
+
+typedef struct sgx_handle sgx_handle;
+
+/* The list .init_nullmod builds (R/assoc_single.r:28-66) as read by
+ * saige_score_test_init (src/saige_main.cpp:106-130).  K x N matrices are
+ * column-major, i.e. the K values of sample i are contiguous at [K*i]. */
+typedef struct sgx_model {
+	int32_t n_samp;              /* N  = length(y)                  :117 */
+	int32_t n_coeff;             /* K  = nrow(XV)                   :118 */
+	int32_t trait;               /* SGX_TRAIT_*                          */
+	int32_t reserved;
+	double tau[2];               /* variance components             :119 */
+	double var_ratio;            /* var.ratio                       :130 */
+	double maf;                  /* thresholds; NaN -> -1/-1/1/0.05 :108-115 */
+	double mac;
+	double missing;
+	double spa_pval;
+	const double *y;             /* N                               :120 */
+	const double *mu;            /* N                               :121 */
+	const double *y_mu;          /* N   y - mu                      :122 */
+	const double *mu2;           /* N   mu*(1-mu)                   :123 */
+	const double *t_XXVX_inv;    /* K x N                           :124 */
+	const double *XV;            /* K x N                           :125 */
+	const double *t_XVX_inv_XV;  /* K x N                           :126 */
+	const double *XVX;           /* K x K                           :127 */
+	const double *t_X;           /* K x N                           :128 */
+	const double *S_a;           /* K                               :129 */
+} sgx_model;
+
+/* Counters and device timings of the most recent scan call on a handle. */
+typedef struct sgx_stats {
+	uint64_t n_variants;   /* variants in the call                            */
+	uint64_t n_valid;      /* passed the filter                               */
+	uint64_t n_spa;        /* pval_noadj <= spa.pval, handed to the SPA stage */
+	float ms_score;        /* HIP-event time of the score kernel(s), ms       */
+	float ms_spa;          /* HIP-event time of the SPA kernel(s), ms         */
+	float ms_total;        /* first launch .. last launch complete, ms        */
+	uint32_t score_launches;
+	uint32_t spa_launches;
+} sgx_stats;
+
+/* Library / device ------------------------------------------------------- */
+const char *sgx_version(void);
+const char *sgx_last_error(void);
+int sgx_device_count(void);
+
+/* Model lifetime (one handle per GPU; handles are independent, no globals). */
+int  sgx_init(const sgx_model *model, int device, sgx_handle **out);
+void sgx_free(sgx_handle *h);
+int  sgx_set_thresholds(sgx_handle *h, double maf, double mac, double missing,
+	double spa_pval);
+
+/* Scan a block of variants held in HOST memory.  packed: n_variants rows of
+ * bytes_per_variant bytes (>= ceil(N/4)).  out8: n_variants*8 doubles.
+ * valid: n_variants bytes.  Synchronous. */
+int sgx_scan_2bit(sgx_handle *h, const uint8_t *packed, size_t bytes_per_variant,
+	size_t n_variants, double *out8, uint8_t *valid);
+
+/* Same, all buffers already resident in this GPU's HBM (device pointers).
+ * packed must be 16-byte aligned and bytes_per_variant a multiple of 16 with
+ * bytes_per_variant >= 16*ceil(N/64).  Asynchronous on the handle's stream;
+ * call sgx_sync() before reading results or stats. */
+int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev,
+	size_t bytes_per_variant, size_t n_variants, double *out8_dev,
+	uint8_t *valid_dev);
+
+/* Dosage inputs in HOST memory, one row of N values per variant:
+ *   u8 : 0..254, 0xFF = missing (RAWSXP);  f64: NaN/Inf = missing (REALSXP). */
+int sgx_scan_u8(sgx_handle *h, const uint8_t *dosage, size_t n_variants,
+	double *out8, uint8_t *valid);
+int sgx_scan_f64(sgx_handle *h, const double *dosage, size_t n_variants,
+	double *out8, uint8_t *valid);
+
+int sgx_sync(sgx_handle *h);
+int sgx_get_stats(sgx_handle *h, sgx_stats *st);
+
+/* Device-side helpers for the benchmark / synthetic GDS generator ---------- */
+
+/* Smallest legal bytes_per_variant for sgx_scan_2bit_dev. */
+size_t sgx_row_stride(int32_t n_samp);
+
+/* Fill packed_dev (n_variants rows of bytes_per_variant) with synthetic 2-bit
+ * genotypes: sample i of variant (first_variant+j) draws one 64-bit
+ * counter-based random word (splitmix64 of seed, variant, sample); the top 32
+ * bits u pick the code: u < thr[3j] -> 0, u < thr[3j+1] -> 1, else 2; the low
+ * 32 bits v mark it missing when v < thr[3j+2].  thr_dev: n_variants*3 uint32
+ * in device memory.  The same function in numpy: saigegds_amd/synth.py. */
+int sgx_synth_2bit_dev(sgx_handle *h, uint8_t *packed_dev, size_t bytes_per_variant,
+	int32_t n_samp, size_t n_variants, uint64_t first_variant, uint64_t seed,
+	const uint32_t *thr_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAIGEHIP_H */

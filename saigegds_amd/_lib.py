@@ -1,0 +1,194 @@
+"""ctypes binding of libsaigehip.so (include/saigehip.h).
+
+There is no CPU fallback: if the HIP library is missing or no MI355X is
+visible, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsaigehip.so")
+
+EXPORTS = (
+    "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
+    "sgx_set_thresholds", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64",
+    "sgx_sync", "sgx_get_stats", "sgx_row_stride", "sgx_synth_2bit_dev",
+)
+
+
+class SgxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsaigehip error {code}: {msg}")
+        self.code = code
+
+
+class SgxModel(C.Structure):
+    _fields_ = [
+        ("n_samp", C.c_int32), ("n_coeff", C.c_int32), ("trait", C.c_int32), ("reserved", C.c_int32),
+        ("tau", C.c_double * 2), ("var_ratio", C.c_double),
+        ("maf", C.c_double), ("mac", C.c_double), ("missing", C.c_double), ("spa_pval", C.c_double),
+        ("y", C.c_void_p), ("mu", C.c_void_p), ("y_mu", C.c_void_p), ("mu2", C.c_void_p),
+        ("t_XXVX_inv", C.c_void_p), ("XV", C.c_void_p), ("t_XVX_inv_XV", C.c_void_p),
+        ("XVX", C.c_void_p), ("t_X", C.c_void_p), ("S_a", C.c_void_p),
+    ]
+
+
+class SgxStats(C.Structure):
+    _fields_ = [
+        ("n_variants", C.c_uint64), ("n_valid", C.c_uint64), ("n_spa", C.c_uint64),
+        ("ms_score", C.c_float), ("ms_spa", C.c_float), ("ms_total", C.c_float),
+        ("score_launches", C.c_uint32), ("spa_launches", C.c_uint32),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def load():
+    """Load libsaigehip.so; raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `make -C saigegds_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, dp = C.c_void_p, C.c_size_t, C.c_double
+    L.sgx_version.restype = C.c_char_p
+    L.sgx_last_error.restype = C.c_char_p
+    L.sgx_device_count.restype = C.c_int
+    L.sgx_init.restype = C.c_int
+    L.sgx_init.argtypes = [C.POINTER(SgxModel), C.c_int, C.POINTER(vp)]
+    L.sgx_free.restype = None
+    L.sgx_free.argtypes = [vp]
+    L.sgx_set_thresholds.restype = C.c_int
+    L.sgx_set_thresholds.argtypes = [vp, dp, dp, dp, dp]
+    L.sgx_scan_2bit.restype = C.c_int
+    L.sgx_scan_2bit.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.sgx_scan_2bit_dev.restype = C.c_int
+    L.sgx_scan_2bit_dev.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.sgx_scan_u8.restype = C.c_int
+    L.sgx_scan_u8.argtypes = [vp, vp, sz, vp, vp]
+    L.sgx_scan_f64.restype = C.c_int
+    L.sgx_scan_f64.argtypes = [vp, vp, sz, vp, vp]
+    L.sgx_sync.restype = C.c_int
+    L.sgx_sync.argtypes = [vp]
+    L.sgx_get_stats.restype = C.c_int
+    L.sgx_get_stats.argtypes = [vp, C.POINTER(SgxStats)]
+    L.sgx_row_stride.restype = sz
+    L.sgx_row_stride.argtypes = [C.c_int32]
+    L.sgx_synth_2bit_dev.restype = C.c_int
+    L.sgx_synth_2bit_dev.argtypes = [vp, vp, sz, C.c_int32, sz, C.c_uint64, C.c_uint64, vp]
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise SgxError(rc, load().sgx_last_error().decode("utf-8", "replace"))
+
+
+class Scanner:
+    """One model resident on one GPU (an ``sgx_handle``)."""
+
+    def __init__(self, sm, device: int = 0):
+        L = load()
+        self._L = L
+        self.n, self.k, self.quant = sm.n, sm.k, sm.quant
+        f = lambda a: np.ascontiguousarray(a, dtype=np.float64)  # noqa: E731
+        self._keep = dict(y=f(sm.y), mu=f(sm.mu), y_mu=f(sm.y_mu), mu2=f(sm.mu2),
+                          t_XXVX_inv=f(sm.t_XXVX_inv), XV=f(sm.XV), t_XVX_inv_XV=f(sm.t_XVX_inv_XV),
+                          XVX=f(sm.XVX), t_X=f(sm.t_X), S_a=f(sm.S_a))
+        m = SgxModel()
+        m.n_samp, m.n_coeff = sm.n, sm.k
+        m.trait = 1 if sm.quant else 0
+        m.tau[0], m.tau[1] = float(sm.tau[0]), float(sm.tau[1])
+        m.var_ratio = sm.var_ratio
+        m.maf, m.mac, m.missing, m.spa_pval = sm.maf, sm.mac, sm.missing, sm.spa_pval
+        for k, a in self._keep.items():
+            setattr(m, k, a.ctypes.data)
+        h = C.c_void_p()
+        check(L.sgx_init(C.byref(m), int(device), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    # -- lifetime --------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sgx_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- host-buffer scans -------------------------------------------------
+    def _out(self, m):
+        return np.empty((m, 8), dtype=np.float64), np.zeros(m, dtype=np.uint8)
+
+    def scan_2bit(self, packed: np.ndarray):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        if packed.ndim != 2:
+            raise ValueError("packed genotypes must be [n_variants, bytes_per_variant]")
+        m, bpv = packed.shape
+        out, valid = self._out(m)
+        check(self._L.sgx_scan_2bit(self._h, packed.ctypes.data, bpv, m, out.ctypes.data,
+                                    valid.ctypes.data))
+        return out, valid
+
+    def scan_u8(self, dosage: np.ndarray):
+        dosage = np.ascontiguousarray(dosage, dtype=np.uint8)
+        if dosage.ndim != 2 or dosage.shape[1] != self.n:
+            raise ValueError(f"Invalid length of dosages: {dosage.shape[-1]}.")
+        out, valid = self._out(dosage.shape[0])
+        check(self._L.sgx_scan_u8(self._h, dosage.ctypes.data, dosage.shape[0], out.ctypes.data,
+                                  valid.ctypes.data))
+        return out, valid
+
+    def scan_f64(self, dosage: np.ndarray):
+        dosage = np.ascontiguousarray(dosage, dtype=np.float64)
+        if dosage.ndim != 2 or dosage.shape[1] != self.n:
+            raise ValueError(f"Invalid length of dosages: {dosage.shape[-1]}.")
+        out, valid = self._out(dosage.shape[0])
+        check(self._L.sgx_scan_f64(self._h, dosage.ctypes.data, dosage.shape[0], out.ctypes.data,
+                                   valid.ctypes.data))
+        return out, valid
+
+    # -- device-resident scans (pointers are raw device addresses) ---------
+    def row_stride(self) -> int:
+        return int(self._L.sgx_row_stride(self.n))
+
+    def scan_2bit_dev(self, packed_ptr: int, bpv: int, m: int, out_ptr: int, valid_ptr: int):
+        check(self._L.sgx_scan_2bit_dev(self._h, packed_ptr, bpv, m, out_ptr, valid_ptr))
+
+    def synth_2bit_dev(self, packed_ptr: int, bpv: int, m: int, first_variant: int, seed: int,
+                       thr_ptr: int):
+        check(self._L.sgx_synth_2bit_dev(self._h, packed_ptr, bpv, self.n, m, first_variant, seed,
+                                         thr_ptr))
+
+    def sync(self):
+        check(self._L.sgx_sync(self._h))
+
+    def stats(self) -> dict:
+        st = SgxStats()
+        check(self._L.sgx_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def set_thresholds(self, maf, mac, missing, spa_pval):
+        check(self._L.sgx_set_thresholds(self._h, maf, mac, missing, spa_pval))

@@ -1,0 +1,149 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle
+and the reference's golden tables (inst/unitTests/test_SAIGE.R:79-106)."""
+import numpy as np
+import pytest
+
+from conftest import assert_table_close, scan_model
+
+pytestmark = pytest.mark.gpu
+
+
+def _scanner(sm):
+    from saigegds_amd._lib import Scanner
+    return Scanner(sm, device=0)
+
+
+def _oracle(sm):
+    from oracle import Oracle
+    return Oracle(sm)
+
+
+def _golden_table(g, quant):
+    cols = ["AF_alt", "mac", "num", "beta", "SE", "pval"] + ([] if quant else ["p_norm", "converged"])
+    t = np.full((g["AF_alt"].size, 8), np.nan)
+    for c, n in enumerate(cols):
+        t[:, c] = g[n].astype(np.float64)
+    return t
+
+
+def test_golden_binary(grm1k, model_bin, golden_bin):
+    """test.saige_pval, binary: all 10 000 variants, mac=4."""
+    with _scanner(model_bin) as sc:
+        out, valid = sc.scan_2bit(grm1k["packed"])
+        st = sc.stats()
+    assert st["n_spa"] == 436 and st["n_valid"] == 10000
+    ref = _golden_table(golden_bin, False)
+    assert_table_close(out, valid, ref, np.ones(10000, np.uint8), what="golden binary")
+    oref, ovalid = _oracle(model_bin).scan_2bit(grm1k["packed"])
+    assert_table_close(out, valid, oref, ovalid, what="oracle binary")
+
+
+def test_golden_quant(grm1k, model_quant, golden_quant):
+    """test.saige_pval, quantitative."""
+    with _scanner(model_quant) as sc:
+        out, valid = sc.scan_2bit(grm1k["packed"])
+    ref = _golden_table(golden_quant, True)
+    assert_table_close(out, valid, ref, np.ones(10000, np.uint8), quant=True, what="golden quant")
+    oref, ovalid = _oracle(model_quant).scan_2bit(grm1k["packed"])
+    assert_table_close(out, valid, oref, ovalid, quant=True, what="oracle quant")
+
+
+def _synthetic_case(n, m, trait, prevalence, seed, k=3, miss=1e-2, flip=0.3, lo=-2.5):
+    from saigegds_amd import synth
+    from saigegds_amd.nullmod import init_nullmod
+    mod = synth.synth_null_model(n, trait, prevalence, n_cov=k, seed=seed)
+    sm = init_nullmod(mod, np.arange(n), float("nan"), 10, 0.1, 0.05, float(mod.var_ratio[0]))
+    thr = synth.variant_thresholds(0, m, seed, log10_maf=(lo, -0.3), flip_frac=flip, miss_rate=miss)
+    packed = synth.synth_packed(n, 0, m, seed, thr)
+    return sm, packed
+
+
+@pytest.mark.parametrize("trait,prev", [("binary", 0.1), ("binary", 0.02), ("quantitative", 0.0)])
+def test_synthetic_flip_missing(trait, prev):
+    """Branches the goldens never reach: AF>0.5 flip, missing genotypes (imputed
+    2*AF), filter rejections; ragged N (not a multiple of 64)."""
+    sm, packed = _synthetic_case(3001, 1500, trait, prev, seed=7)
+    orc = _oracle(sm)
+    ref, ref_valid = orc.scan_2bit(packed)
+    tr = orc.trace.as_dict()
+    assert (ref_valid == 0).any() and (ref_valid == 1).any()
+    if trait == "binary":
+        assert tr["flipped"] > 50 and tr["spa_done"] > 10
+    with _scanner(sm) as sc:
+        out, valid = sc.scan_2bit(packed)
+    assert_table_close(out, valid, ref, ref_valid, quant=sm.quant, what=f"synthetic {trait}")
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 8, 13, 16])
+def test_covariate_counts(k):
+    sm, packed = _synthetic_case(2000, 400, "binary", 0.1, seed=11 + k, k=k)
+    ref, ref_valid = _oracle(sm).scan_2bit(packed)
+    with _scanner(sm) as sc:
+        out, valid = sc.scan_2bit(packed)
+    assert_table_close(out, valid, ref, ref_valid, what=f"K={k}")
+
+
+def test_dosage_inputs(grm1k, model_bin):
+    """RAW and REAL branches of get_ds (saige_main.cpp:171-183)."""
+    from saigegds_amd.gds import unpack_dosage_2bit
+    ds = unpack_dosage_2bit(grm1k["packed"][:2000], 1000)
+    ds[5, 17] = 0xFF
+    ds[9, :40] = 0xFF
+    orc = _oracle(model_bin)
+    ref, ref_valid = orc.scan_u8(ds)
+    with _scanner(model_bin) as sc:
+        out, valid = sc.scan_u8(ds)
+        assert_table_close(out, valid, ref, ref_valid, what="u8 dosage")
+        dsf = ds.astype(np.float64)
+        dsf[ds == 0xFF] = np.nan
+        dsf[100:200] *= 0.93          # real-valued dosages: AF/mac no longer integers
+        ref2, ref_valid2 = orc.scan_f64(dsf)
+        out2, valid2 = sc.scan_f64(dsf)
+    assert np.array_equal(valid2, ref_valid2)
+    v = ref_valid2.astype(bool)
+    # integer genotype rows stay bit-exact; real-valued ones differ by summation order
+    np.testing.assert_allclose(out2[v][:, :3], ref2[v][:, :3], rtol=1e-13)
+    for c in (3, 4, 5, 6):
+        np.testing.assert_allclose(out2[v][:, c], ref2[v][:, c], rtol=1e-9)
+
+
+def test_empty_and_errors(model_bin):
+    from saigegds_amd._lib import SgxError
+    with _scanner(model_bin) as sc:
+        out, valid = sc.scan_2bit(np.zeros((0, 250), np.uint8))
+        assert out.shape == (0, 8) and valid.shape == (0,)
+        with pytest.raises(SgxError):          # ERR_DS_LEN, saige_main.cpp:157,417-418
+            sc.scan_2bit(np.zeros((3, 100), np.uint8))
+        # monomorphic and all-missing variants are filtered, not crashed on
+        pk = np.zeros((2, 250), np.uint8)
+        pk[1] = 0xFF
+        out, valid = sc.scan_2bit(pk)
+        assert not valid.any() and np.isnan(out).all()
+
+
+def test_device_resident_and_generator():
+    """sgx_scan_2bit_dev on HBM-resident rows produced by sgx_synth_2bit_dev;
+    the numpy twin of the generator must give identical bytes."""
+    import torch
+    from saigegds_amd import synth
+    from saigegds_amd.nullmod import init_nullmod
+    n, m, seed = 5000, 3000, 20260
+    mod = synth.synth_null_model(n, "binary", 0.05, seed=seed)
+    sm = init_nullmod(mod, np.arange(n), float("nan"), 10, 0.1, 0.05, float(mod.var_ratio[0]))
+    thr = synth.variant_thresholds(100, m, seed)
+    with _scanner(sm) as sc:
+        bpv = sc.row_stride()
+        dev = torch.device("cuda:0")
+        packed = torch.zeros((m, bpv), dtype=torch.uint8, device=dev)
+        thr_d = torch.from_numpy(thr.view(np.int32)).to(dev)
+        out = torch.empty((m, 8), dtype=torch.float64, device=dev)
+        valid = torch.empty((m,), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        sc.synth_2bit_dev(packed.data_ptr(), bpv, m, 100, seed, thr_d.data_ptr())
+        sc.scan_2bit_dev(packed.data_ptr(), bpv, m, out.data_ptr(), valid.data_ptr())
+        sc.sync()
+        pk_host = packed.cpu().numpy()
+        out_h, valid_h = out.cpu().numpy(), valid.cpu().numpy()
+    assert np.array_equal(pk_host, synth.synth_packed(n, 100, m, seed, thr, bpv))
+    ref, ref_valid = _oracle(sm).scan_2bit(pk_host)
+    assert_table_close(out_h, valid_h, ref, ref_valid, what="device-resident")
