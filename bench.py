@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""Benchmark of the single-variant SPA scan (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (score kernel + SPA kernel, through
+sgx_scan_2bit_dev) over one block of 50 000 variants (the reference's
+seqParallel block size, R/assoc_single.r:204) of synthetic 2-bit genotypes that
+are already resident in this GPU's HBM.  Every step scans a different block.
+
+Workloads; variants shard across ranks, per-GPU work is
+fixed (weak scaling); with 8 GPUs and 25 steps the job is BASELINE config [2]:
+  c3 (default)  N=430 000, binary trait, prevalence 0.01 (1:99), K=3
+  c2            N= 50 000, binary trait, prevalence 0.10 (1:9),  K=3
+  c4            N=430 000, quantitative trait (no SPA), K=3
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    "c3": dict(n=430_000, trait="binary", prevalence=0.01, desc="configs[2] shard"),
+    "c2": dict(n=50_000, trait="binary", prevalence=0.10, desc="configs[1]"),
+    "c4": dict(n=430_000, trait="quantitative", prevalence=0.0, desc="configs[3] shard"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--block", type=int, default=50_000, help="variants per step")
+    ap.add_argument("--k", type=int, default=3, help="covariates incl. intercept")
+    ap.add_argument("--n-samp", type=int, default=0, help="override N (debug)")
+    ap.add_argument("--pool-gb", type=float, default=120.0, help="max HBM for resident genotypes")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
+    ap.add_argument("--seed", type=int, default=20260)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from saigegds_amd import synth
+    from saigegds_amd._lib import Scanner
+    from saigegds_amd.nullmod import init_nullmod
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    wl = dict(WORKLOADS[args.workload])
+    if args.n_samp:
+        wl["n"] = args.n_samp
+    n, block, steps, warmup = wl["n"], args.block, args.steps, args.warmup
+
+    # ---- model (identical on every rank) --------------------------------
+    mod = synth.synth_null_model(n, wl["trait"], wl["prevalence"], n_cov=args.k, seed=args.seed)
+    sm = init_nullmod(mod, np.arange(n), float("nan"), 10.0, 0.1, 0.05, float(mod.var_ratio[0]))
+    sc = Scanner(sm, device=local)
+    bpv = sc.row_stride()
+
+    # ---- HBM-resident genotype pool --------------------------------------
+    want = steps + warmup
+    pool = max(1, min(want, int(args.pool_gb * 1e9 // (block * bpv))))
+    packed = torch.empty((pool, block, bpv), dtype=torch.uint8, device=dev)
+    out = torch.empty((pool, block, 8), dtype=torch.float64, device=dev)
+    valid = torch.empty((pool, block), dtype=torch.uint8, device=dev)
+    t_gen = time.time()
+    for b in range(pool):
+        first = (rank * pool + b) * block
+        thr = synth.variant_thresholds(first, block, args.seed)
+        thr_d = torch.from_numpy(thr.view(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        sc.synth_2bit_dev(packed[b].data_ptr(), bpv, block, first, args.seed, thr_d.data_ptr())
+        sc.sync()
+    t_gen = time.time() - t_gen
+
+    def run_step(i):
+        b = i % pool
+        sc.scan_2bit_dev(packed[b].data_ptr(), bpv, block, out[b].data_ptr(), valid[b].data_ptr())
+        return sc.stats()       # syncs the handle's stream; HIP-event kernel times
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        run_step(i)
+
+    # ---- timed region -------------------------------------------------------
+    barrier()
+    t0 = time.perf_counter()
+    st_all = []
+    for i in range(steps):
+        st_all.append(run_step(warmup + i))
+    if world > 1:
+        # the path's one exchange step: result table to rank 0
+        used = sorted({(warmup + i) % pool for i in range(steps)})
+        tab = out[used].reshape(-1, 8)
+        gathered = [torch.empty_like(tab) for _ in range(world)] if rank == 0 else None
+        dist.gather(tab, gathered, dst=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # ---- per-kernel figures (rank 0's launches) ----------------------------
+    ms_score = float(np.mean([s["ms_score"] for s in st_all]))
+    ms_spa = float(np.mean([s["ms_spa"] for s in st_all]))
+    n_spa = int(np.sum([s["n_spa"] for s in st_all]))
+    n_valid = int(np.sum([s["n_valid"] for s in st_all]))
+    nv_tot = steps * block
+    alg_bytes = block * (math.ceil(n / 4) + 64)      # ceil(N/4)+64 B per variant
+    dom = "score2b_kernel" if ms_score >= ms_spa else "spa_kernel"
+    dom_ms = max(ms_score, ms_spa)
+    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    roofline = {
+        "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
+        "kernels": {
+            "score2b_kernel": {"avg_ms": round(ms_score, 4),
+                               "hbm_gbs": round(alg_bytes / (ms_score * 1e-3) / 1e9, 2) if ms_score > 0 else None},
+            "spa_kernel": {"avg_ms": round(ms_spa, 4), "variants_per_launch": n_spa / max(1, steps)},
+        },
+        "whole_step_gbs": round(alg_bytes * steps / elapsed / 1e9, 2),
+    }
+
+    # ---- CPU baseline + parity spot-check (rank 0, N=1 only) ---------------
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        from oracle import Oracle
+        b0 = warmup % pool
+        orc = Oracle(sm)
+        pilot = packed[b0, :64].cpu().numpy()
+        t = time.perf_counter()
+        orc.scan_2bit(pilot)
+        per = (time.perf_counter() - t) / 64
+        ns = int(max(64, min(block, args.cpu_seconds / max(per, 1e-9))))
+        sample = packed[b0, :ns].cpu().numpy()
+        t = time.perf_counter()
+        ref, ref_valid = orc.scan_2bit(sample)
+        dt = time.perf_counter() - t
+        got, got_valid = out[b0, :ns].cpu().numpy(), valid[b0, :ns].cpu().numpy()
+        ok = np.array_equal(got_valid, ref_valid)
+        v = ref_valid.astype(bool)
+        cols = [3, 4, 5] + ([] if sm.quant else [6])
+        a, r = got[v][:, cols], ref[v][:, cols]
+        with np.errstate(invalid="ignore", divide="ignore"):
+            rel = np.where(a == r, 0.0, np.abs(a - r) / np.abs(r))
+        ok = ok and np.array_equal(got[v][:, :3], ref[v][:, :3])
+        cpu = {"value": round(ns / dt, 2), "unit": "variants/s", "cores": 1, "kind": "port",
+               "sample": f"first {ns} variants of timed block {b0} (same data as the GPU), "
+                         f"oracle/saige_oracle.c single thread",
+               "seconds": round(dt, 2), "parity_ok": bool(ok and np.nanmax(rel) <= 1e-10),
+               "parity_max_rel": float(np.nanmax(rel)) if rel.size else 0.0}
+
+    if rank == 0:
+        line = {
+            "metric": "variants/sec seqAssocGLMM_SPA at N=430K; achieved HBM GB/s vs roofline",
+            "value": round(nv_tot * world / elapsed, 1), "unit": "variants/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: {wl['desc']}, N={n} samples x {block} variants/step/GPU, "
+                            f"{wl['trait']} trait" + (f" prevalence {wl['prevalence']}" if wl['trait'] == 'binary' else ""),
+                "n_samples": n, "variants_per_step_per_gpu": block, "n_covariates": args.k,
+                "maf_law": "10^U(-3.3,-0.3), 10% alt-major, missing 1e-3", "thresholds": "mac=10 missing=0.1 spa.pval=0.05",
+                "resident_blocks": pool, "sharding": f"variants x{world}",
+                "frac_spa": round(n_spa / max(1, nv_tot), 5), "frac_valid": round(n_valid / max(1, nv_tot), 5),
+                "gen_seconds": round(t_gen, 2),
+            },
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    sc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,6 +51,25 @@ class SgxStats(C.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so.  Two HIP runtimes in one
+    process cannot both open the GPU, so when torch is installed its copy is
+    loaded first; libsaigehip.so (NEEDED libamdhip64.so.7) then binds to it by
+    SONAME.  Without torch (e.g. under R) the system ROCm runtime is used."""
+    if os.environ.get("SAIGEHIP_SYSTEM_HIP") == "1":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 def load():
     """Load libsaigehip.so; raises if it has not been built."""
     global _lib
@@ -60,6 +79,7 @@ def load():
         raise ImportError(
             f"{LIB_PATH} not found: build it with `make -C saigegds_amd/csrc` "
             "(or __graft_entry__.build()).  There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     vp, sz, dp = C.c_void_p, C.c_size_t, C.c_double
     L.sgx_version.restype = C.c_char_p
