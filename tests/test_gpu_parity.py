@@ -147,3 +147,32 @@ def test_device_resident_and_generator():
     assert np.array_equal(pk_host, synth.synth_packed(n, 100, m, seed, thr, bpv))
     ref, ref_valid = _oracle(sm).scan_2bit(pk_host)
     assert_table_close(out_h, valid_h, ref, ref_valid, what="device-resident")
+
+
+def test_seqAssocGLMM_SPA_driver(grm1k, golden_bin, tmp_path):
+    """test.saige_pval through the host driver: data.frame columns, filter
+    intersection (mac=40 drops variants), sample subset + reorder, .rds output."""
+    from conftest import load_null_model
+    from saigegds_amd import GenotypeSource, seqAssocGLMM_SPA
+    from saigegds_amd.rds import read_rds
+    mod = load_null_model("saige_model.npz")
+    sid = [str(s) for s in grm1k["sample_id"]]
+    src = GenotypeSource(sid, packed=grm1k["packed"], variant_id=grm1k["variant_id"],
+                         chromosome=[str(c) for c in grm1k["chromosome"]], position=grm1k["position"],
+                         rs_id=[str(c) for c in grm1k["rs_id"]], ref=[str(c) for c in grm1k["ref"]],
+                         alt=[str(c) for c in grm1k["alt"]])
+    ans = seqAssocGLMM_SPA(src, mod, mac=4, verbose=False)
+    assert list(ans) == ["id", "chr", "pos", "rs.id", "ref", "alt", "AF.alt", "mac", "num", "beta",
+                         "SE", "pval", "p.norm", "converged"]
+    assert np.array_equal(ans["id"], golden_bin["id"]) and ans["rs.id"][:2] == ["rs1", "rs2"]
+    assert np.array_equal(ans["AF.alt"], golden_bin["AF_alt"]) and ans["num"].dtype == np.int32
+    for c, g in (("beta", "beta"), ("SE", "SE"), ("pval", "pval"), ("p.norm", "p_norm")):
+        assert np.max(np.abs(ans[c] / golden_bin[g] - 1)) <= 1e-10, c
+    assert np.array_equal(ans["converged"], golden_bin["converged"])
+    # stricter MAC filter -> fewer rows, same values on the survivors
+    fn = str(tmp_path / "out.rds")
+    assert seqAssocGLMM_SPA(src, mod, mac=40, res_savefn=fn, verbose=False) is None
+    r = read_rds(fn)
+    keep = golden_bin["mac"] >= 40
+    assert 0 < keep.sum() < 10000 and np.array_equal(np.asarray(r["id"]), golden_bin["id"][keep])
+    assert np.max(np.abs(np.asarray(r["pval"]) / golden_bin["pval"][keep] - 1)) <= 1e-10

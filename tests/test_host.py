@@ -1,0 +1,135 @@
+"""CPU tests: host logic, file formats, ABI surface (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, REFERENCE, ROOT, load_null_model
+
+
+def test_abi_exports_every_declared_symbol():
+    """libsaigehip.so loads and exports exactly what include/saigehip.h declares."""
+    from saigegds_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "saigehip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(sgx_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS)
+    L = _lib.load()
+    for s in declared:
+        assert hasattr(L, s), s
+    assert b"gfx950" in L.sgx_version()
+    assert L.sgx_row_stride(430000) == 107504 and L.sgx_row_stride(1000) == 256
+    # struct layouts agree with the header (sizes the C side computes)
+    assert ctypes.sizeof(_lib.SgxModel) == 4 * 4 + 7 * 8 + 10 * 8
+    assert ctypes.sizeof(_lib.SgxStats) == 3 * 8 + 3 * 4 + 2 * 4 + 4
+
+
+def test_init_rejects_bad_models_without_gpu():
+    from saigegds_amd import _lib
+    L = _lib.load()
+    h = ctypes.c_void_p()
+    m = _lib.SgxModel()
+    assert L.sgx_init(None, 0, ctypes.byref(h)) == -1
+    m.n_samp, m.n_coeff = 10, 99
+    assert L.sgx_init(ctypes.byref(m), 0, ctypes.byref(h)) == -1
+    assert b"n_coeff" in L.sgx_last_error()
+
+
+def test_init_nullmod_matches_reference_layout():
+    """.init_nullmod (R/assoc_single.r:17-67): shapes, orientation, derived terms."""
+    from saigegds_amd.nullmod import init_nullmod, ModelError
+    mod = load_null_model("saige_model.npz")
+    n = len(mod.sample_id)
+    perm = np.random.default_rng(0).permutation(n)
+    sm = init_nullmod(mod, perm, float("nan"), 4, 0.1, 0.05, 0.9)
+    assert sm.k == 3 and sm.n == n and sm.t_X.shape == (n, 3) and sm.XVX.shape == (3, 3)
+    assert np.array_equal(sm.y, mod.y[perm]) and np.array_equal(sm.mu, mod.fitted_values[perm])
+    assert np.array_equal(sm.y_mu, (mod.y - mod.fitted_values)[perm])
+    assert np.array_equal(sm.XV, mod.XV[:, perm].T)
+    assert np.allclose(sm.t_XVX_inv_XV, mod.XXVX_inv[perm] * mod.V[perm, None], rtol=0, atol=0)
+    assert np.allclose(sm.XVX, sm.t_X.T @ (sm.t_X * sm.mu2[:, None]))
+    assert np.allclose(sm.S_a, (sm.t_X * sm.y_mu[:, None]).sum(0))
+    with pytest.raises(ModelError, match="Invalid variance ratio"):
+        init_nullmod(mod, perm, float("nan"), 4, 0.1, 0.05, float("nan"))
+    q = init_nullmod(load_null_model("saige_model_quant.npz"), np.arange(n), 0, 0, 1, 0.05, 1.0)
+    assert np.allclose(q.XVX, q.t_X.T @ q.t_X)
+
+
+def test_assoc_argument_checks():
+    """stopifnot()s and messages of seqAssocGLMM_SPA (R/assoc_single.r:96-107,138-142)."""
+    from saigegds_amd import GenotypeSource, seqAssocGLMM_SPA
+    from saigegds_amd.nullmod import ModelError
+    mod = load_null_model("saige_model.npz")
+    z = np.load(os.path.join(GOLDEN, "grm1k_10k_snp.npz"))
+    src = GenotypeSource([str(s) for s in z["sample_id"]], packed=z["packed"][:10])
+    with pytest.raises(TypeError):
+        seqAssocGLMM_SPA(src, mod, maf="x", verbose=False)
+    with pytest.raises(ValueError, match="res.compress"):
+        seqAssocGLMM_SPA(src, mod, res_compress="bz2", verbose=False)
+    with pytest.raises(TypeError):
+        seqAssocGLMM_SPA(12, mod, verbose=False)
+    short = GenotypeSource([str(s) for s in z["sample_id"][:900]],
+                           packed=np.zeros((10, 225), np.uint8))
+    with pytest.raises(ModelError, match="Some of sample IDs are not available"):
+        seqAssocGLMM_SPA(short, mod, verbose=False)
+    with pytest.raises(ModelError):
+        seqAssocGLMM_SPA(src, 3.5, verbose=False)
+
+
+def test_shard_ranges_cover_in_order():
+    from saigegds_amd.dist import shard_range
+    for m in (0, 1, 7, 8, 9, 10_000_000):
+        for w in (1, 2, 3, 8):
+            r = [shard_range(m, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == m
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+def test_result_writers_roundtrip(tmp_path):
+    from saigegds_amd.rds import read_rds
+    from saigegds_amd.results import save_result
+    z = np.load(os.path.join(GOLDEN, "saige_pval.npz"))
+    ans = {"id": z["id"], "chr": [str(s) for s in z["chr"]], "AF.alt": z["AF_alt"],
+           "num": z["num"].astype(np.int32), "pval": z["pval"], "converged": z["converged"]}
+    for cm in ("LZMA", "ZIP", "none"):
+        fn = str(tmp_path / "res.rds")
+        save_result(ans, fn, cm)
+        r = read_rds(fn)
+        assert r.rclass() == ["data.frame"] and r.names == list(ans)
+        assert np.array_equal(np.asarray(r["pval"]), ans["pval"])
+        assert list(r["chr"]) == ans["chr"] and np.array_equal(np.asarray(r["converged"]), ans["converged"])
+    with pytest.raises(ValueError, match="Unknown format"):
+        save_result(ans, str(tmp_path / "res.txt"))
+    with pytest.raises(NotImplementedError):
+        save_result(ans, str(tmp_path / "res.gds"))
+
+
+def test_synthetic_generator_is_counter_based():
+    from saigegds_amd import synth
+    thr = synth.variant_thresholds(0, 64, 5)
+    a = synth.synth_packed(777, 0, 64, 5, thr)
+    b = synth.synth_packed(777, 32, 32, 5, thr[32:])
+    assert np.array_equal(a[32:], b)                 # any shard regenerates its rows
+    assert a.shape[1] % 16 == 0 and not a[:, 195:].any()   # padding beyond ceil(N/4) is zero
+
+
+@pytest.mark.reference
+def test_formats_against_reference_files():
+    """RDS + GDS decoders reproduce the committed fixtures from the raw files."""
+    from saigegds_amd.gds import GdsFile
+    from saigegds_amd.nullmod import load_modobj
+    g = GdsFile(REFERENCE + "/inst/extdata/grm1k_10k_snp.gds")
+    packed, n, m = g.dosage_alt_packed()
+    z = np.load(os.path.join(GOLDEN, "grm1k_10k_snp.npz"))
+    assert (n, m) == (1000, 10000) and np.array_equal(packed, z["packed"])
+    assert g.sample_id()[:2] == ["s1", "s2"] and g.read("annotation/id")[0] == "rs1"
+    mod = load_modobj(REFERENCE + "/inst/unitTests/saige_model_quant.rds")
+    ref = load_null_model("saige_model_quant.npz")
+    assert mod.trait_type == "quantitative" and np.array_equal(mod.y, ref.y)
+    g2 = GdsFile(REFERENCE + "/inst/extdata/assoc_100snp.gds")
+    assert not g2.has_genotype()
+    ds = g2.dosage_real()
+    assert ds.shape == (100, 1000) and set(np.unique(ds)) == {0.0, 1.0, 2.0}
