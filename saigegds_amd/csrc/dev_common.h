@@ -1,0 +1,249 @@
+// dev_common.h -- device model, Rmath stand-ins, reductions, 2-bit helpers, score epilogue
+// Part of libsaigehip.so (single translation unit: saigehip.hip).
+#pragma once
+
+// ---------------------------------------------------------------------------
+// device-side model
+
+struct DevModel {
+	int N, K, P, quant;
+	double tau0, r;
+	double thr_maf, thr_mac, thr_missing, thr_spa;
+	const double *F;    // [N][P] score vectors
+	const double *X;    // [N][K] t_X
+	const double *y;    // [N]
+	const double *mu;   // [N]
+	const double *mu2;  // [N]
+	const double *XM;   // [N][(K+2)&~1]: X_i (K), mu_i, pad -- one gather per carrier in the SPA stage
+	double XVX[KMAX * KMAX];
+	double S_a[KMAX];
+	double Xmu[KMAX];   // X' mu
+	double Xsum[KMAX];  // X' 1
+};
+
+// a variant handed from the score stage to the SPA stage
+struct SpaRec {
+	int j;            // variant index in the block
+	int minus;        // AF > 0.5
+	double lut[4];    // dosage value per 2-bit code after impute + flip
+	double AC2;       // allele count of the tested (minor) allele
+	double p_noadj;
+	double S;         // score sum (y-mu).adj, unscaled
+	double var2;      // sum mu2 adj^2, unscaled (no variance ratio)
+	double c[KMAX];   // c' = XVX_inv_XV * G
+};
+
+// ---------------------------------------------------------------------------
+// device math: Rmath stand-ins (see oracle/saige_oracle.c for the CPU twins)
+
+__device__ __forceinline__ double d_pchisq1_upper(double x)
+{
+	if (isnan(x)) return x;
+	if (x <= 0) return 1.0;
+	return erfc(sqrt(x * 0.5));
+}
+
+__device__ __forceinline__ double d_pnorm_upper(double z) { return 0.5 * erfc(z * M_SQRT1_2); }
+__device__ __forceinline__ double d_pnorm_lower(double z) { return 0.5 * erfc(-z * M_SQRT1_2); }
+
+__device__ __forceinline__ double d_sign(double x)
+{
+	if (isnan(x)) return x;
+	return (x > 0) ? 1.0 : ((x == 0) ? 0.0 : -1.0);
+}
+
+// qnorm(p, 0, 1, lower, log=FALSE): Wichura AS241 PPND16, as Rmath's qnorm5
+__device__ double d_qnorm(double p)
+{
+	if (isnan(p)) return p;
+	if (p < 0 || p > 1) return NAN;
+	if (p == 0) return -INFINITY;
+	if (p == 1) return INFINITY;
+	double q = p - 0.5, r, val;
+	if (fabs(q) <= 0.425) {
+		r = 0.180625 - q * q;
+		val = q * (((((((r * 2509.0809287301226727 +
+			33430.575583588128105) * r + 67265.770927008700853) * r +
+			45921.953931549871457) * r + 13731.693765509461125) * r +
+			1971.5909503065514427) * r + 133.14166789178437745) * r +
+			3.387132872796366608)
+			/ (((((((r * 5226.495278852854561 +
+			28729.085735721942674) * r + 39307.89580009271061) * r +
+			21213.794301586595867) * r + 5394.1960214247511077) * r +
+			687.1870074920579083) * r + 42.313330701600911252) * r + 1.0);
+		return val;
+	}
+	r = (q < 0) ? p : (1.0 - p);
+	r = sqrt(-log(r));
+	if (r <= 5.0) {
+		r -= 1.6;
+		val = (((((((r * 7.7454501427834140764e-4 +
+			0.0227238449892691845833) * r + 0.24178072517745061177) * r +
+			1.27045825245236838258) * r + 3.64784832476320460504) * r +
+			5.7694972214606914055) * r + 4.6303378461565452959) * r +
+			1.42343711074968357734)
+			/ (((((((r * 1.05075007164441684324e-9 +
+			5.475938084995344946e-4) * r + 0.0151986665636164571966) * r +
+			0.14810397642748007459) * r + 0.68976733498510000455) * r +
+			1.6763848301838038494) * r + 2.05319162663775882187) * r + 1.0);
+	} else {
+		r -= 5.0;
+		val = (((((((r * 2.01033439929228813265e-7 +
+			2.71155556874348757815e-5) * r + 0.0012426609473880784386) * r +
+			0.026532189526576123093) * r + 0.29656057182850489123) * r +
+			1.7848265399172913358) * r + 5.4637849111641143699) * r +
+			6.6579046435011037772)
+			/ (((((((r * 2.04426310338993978564e-15 +
+			1.4215117583164458887e-7) * r + 1.8463183175100546818e-5) * r +
+			7.868691311456132591e-4) * r + 0.0148753612908506148525) * r +
+			0.13692988092273580531) * r + 0.59983220655588793769) * r + 1.0);
+	}
+	if (q < 0.0) val = -val;
+	return val;
+}
+
+// ---------------------------------------------------------------------------
+// wavefront / workgroup reductions (deterministic order)
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+	return v;
+}
+
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+	return v;
+}
+
+// Sum NV doubles per thread over the workgroup; every thread gets the totals.
+// sh must hold NV * (BLOCK/64) doubles.  Two barriers.
+template <int NV, int BLOCK>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *sh)
+{
+	constexpr int NW = BLOCK / WAVE;
+	const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+#pragma unroll
+	for (int a = 0; a < NV; a++) {
+		double t = wave_sum(v[a]);
+		if (lane == 0) sh[a * NW + wid] = t;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int a = 0; a < NV; a++) {
+		double t = 0;
+#pragma unroll
+		for (int w = 0; w < NW; w++) t += sh[a * NW + w];
+		v[a] = t;
+	}
+	__syncthreads();
+}
+
+// ---------------------------------------------------------------------------
+// 2-bit helpers.  A dword holds 16 samples; code c of sample s = (w >> 2s) & 3.
+
+#define LO_MASK 0x55555555u
+
+// bit 2s set iff code of sample s != 0
+__device__ __forceinline__ uint32_t nz_fields(uint32_t w) { return (w | (w >> 1)) & LO_MASK; }
+
+// 4-entry table lookup without dynamic register indexing
+__device__ __forceinline__ double sel4(const double (&l)[4], uint32_t code)
+{
+	const double a = (code & 1u) ? l[1] : l[0];
+	const double b = (code & 1u) ? l[3] : l[2];
+	return (code & 2u) ? b : a;
+}
+
+// keep only the first `keep` samples of a dword (keep in [0,16])
+__device__ __forceinline__ uint32_t keep_mask(int keep)
+{
+	return (keep >= 16) ? 0xFFFFFFFFu : ((keep <= 0) ? 0u : ((1u << (2 * keep)) - 1u));
+}
+
+// ---------------------------------------------------------------------------
+// Filter + dosage table shared by every input format.
+//   saige_main.cpp:288-295 (bin) / :197-204 (quant); vectorization.cpp:186-205
+struct VarHead {
+	double AF, AC, mac;
+	int Num, minus, pass;
+	double lut[4];
+};
+
+__device__ __forceinline__ VarHead make_head(const DevModel &md, double AC, int Num)
+{
+	VarHead h;
+	const int N = md.N;
+	h.AC = AC; h.Num = Num;
+	h.AF = (Num > 0) ? (AC / (2 * Num)) : NAN;
+	const double maf = fmin(h.AF, 1 - h.AF);
+	h.mac = fmin(AC, 2 * Num - AC);
+	const double missing = double(N - Num) / N;
+	h.pass = (Num > 0) && (maf > 0) && (maf >= md.thr_maf) && (h.mac >= md.thr_mac) &&
+		(missing <= md.thr_missing);
+	h.minus = h.AF > 0.5;
+	const double imp = 2 * h.AF;
+	if (h.minus) { h.lut[0] = 2; h.lut[1] = 1; h.lut[2] = 0; h.lut[3] = 2 - imp; }
+	else         { h.lut[0] = 0; h.lut[1] = 1; h.lut[2] = 2; h.lut[3] = imp; }
+	return h;
+}
+
+// Score epilogue: from the P reduced sums to the output row; returns 1 when the
+// variant has to go through the SPA stage.
+//   binary saige_main.cpp:313-356, quantitative :225-272
+__device__ int score_epilogue(const DevModel &md, const VarHead &h, const double *acc,
+	double *out, double *c_out, double *p_noadj_out, double *S_out, double *var2_out)
+{
+	const int K = md.K;
+	const double *c = acc, *e = acc + K;
+	const double s = acc[2 * K], w = acc[2 * K + 1];
+	double quad = 0, ec = 0, sac = 0;
+	for (int a = 0; a < K; a++) {
+		const double ca = c[a];
+		for (int b = 0; b < K; b++) quad += ca * c[b] * md.XVX[a * K + b];
+		ec += e[a] * ca;
+		sac += md.S_a[a] * ca;
+	}
+	const double var2 = quad + w - 2 * ec;
+	const double S = s - sac;
+	double pval, beta;
+	if (md.quant) {
+		const double inv_sqrt_mac = 1.0 / sqrt(h.mac), inv_mac = 1.0 / h.mac;
+		const double var1 = var2 * inv_mac * md.r;
+		const double Tstat = S * inv_sqrt_mac / md.tau0;
+		pval = d_pchisq1_upper(Tstat * Tstat / var1);
+		beta = Tstat / var1 * inv_sqrt_mac;
+	} else {
+		const double var1 = var2 * md.r;
+		pval = d_pchisq1_upper(S * S / var1);
+		beta = S / var1;
+	}
+	out[0] = h.AF; out[1] = h.mac; out[2] = h.Num;
+	if (!md.quant) {
+		const int converged = isfinite(pval);
+		if (converged && pval <= md.thr_spa) {
+			for (int a = 0; a < K; a++) c_out[a] = c[a];
+			*p_noadj_out = pval; *S_out = S; *var2_out = var2;
+			out[6] = pval;
+			return 1;
+		}
+		out[6] = pval; out[7] = converged ? 1.0 : 0.0;
+	} else {
+		out[6] = NAN; out[7] = NAN;
+	}
+	if (h.minus) beta = -beta;
+	out[3] = beta;
+	out[4] = fabs(beta / d_qnorm(pval / 2));
+	out[5] = pval;
+	return 0;
+}
+
+__device__ __forceinline__ void nan_row(double *out)
+{
+	const double n = NAN;
+#pragma unroll
+	for (int c = 0; c < 8; c++) out[c] = n;
+}
