@@ -175,11 +175,20 @@ def main():
         with np.errstate(invalid="ignore", divide="ignore"):
             rel = np.where(a == r, 0.0, np.abs(a - r) / np.abs(r))
         ok = ok and np.array_equal(got[v][:, :3], ref[v][:, :3])
+        # the reference algorithm's own rounding noise: the same oracle with long-double sums
+        nl = min(ns, 1500)
+        ld, _ = Oracle(sm, long_double=True).scan_2bit(sample[:nl])
+        vl = ref_valid[:nl].astype(bool)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            e_gpu = np.abs(got[:nl][vl][:, cols] / ld[vl][:, cols] - 1)
+            e_orc = np.abs(ref[:nl][vl][:, cols] / ld[vl][:, cols] - 1)
         cpu = {"value": round(ns / dt, 2), "unit": "variants/s", "cores": 1, "kind": "port",
                "sample": f"first {ns} variants of timed block {b0} (same data as the GPU), "
                          f"oracle/saige_oracle.c single thread",
                "seconds": round(dt, 2), "parity_ok": bool(ok and np.nanmax(rel) <= 1e-10),
-               "parity_max_rel": float(np.nanmax(rel)) if rel.size else 0.0}
+               "parity_max_rel": float(np.nanmax(rel)) if rel.size else 0.0,
+               "gpu_vs_longdouble_max_rel": float(np.nanmax(e_gpu)),
+               "oracle_vs_longdouble_max_rel": float(np.nanmax(e_orc))}
 
     if rank == 0:
         line = {

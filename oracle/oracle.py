@@ -9,7 +9,9 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
+_SO_LD = os.path.join(_HERE, "liboracle_ld.so")
 _lib = None
+_lib_ld = None
 
 
 class OracleTrace(C.Structure):
@@ -23,40 +25,50 @@ class OracleTrace(C.Structure):
 
 def build_oracle(force: bool = False) -> str:
     src = os.path.join(_HERE, "saige_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"],
-                              stdout=subprocess.DEVNULL)
+    for so in (_SO, _SO_LD):
+        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(so)],
+                                  stdout=subprocess.DEVNULL)
     return _SO
 
 
-def _load():
-    global _lib
+def _load(long_double: bool = False):
+    """liboracle.so, or its long-double-accumulator twin (same code, ORC_ACC)."""
+    global _lib, _lib_ld
+    if long_double:
+        if _lib_ld is None:
+            build_oracle()
+            _lib_ld = _bind(C.CDLL(_SO_LD))
+        return _lib_ld
     if _lib is None:
         build_oracle()
-        L = C.CDLL(_SO)
-        dp = C.POINTER(C.c_double)
-        L.orc_model_new.restype = C.c_void_p
-        L.orc_model_new.argtypes = [C.c_int, C.c_int, C.c_int] + [dp] * 11 + [C.c_double] * 5
-        L.orc_model_free.argtypes = [C.c_void_p]
-        for nm in ("orc_scan_f64", "orc_scan_u8"):
-            f = getattr(L, nm)
-            f.restype = C.c_int
-            f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, dp, C.POINTER(C.c_uint8),
-                          C.POINTER(OracleTrace)]
-        L.orc_scan_2bit.restype = C.c_int
-        L.orc_scan_2bit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, dp,
-                                    C.POINTER(C.c_uint8), C.POINTER(OracleTrace)]
-        for nm in ("orc_pchisq1_upper", "orc_qnorm"):
-            getattr(L, nm).restype = C.c_double
-            getattr(L, nm).argtypes = [C.c_double]
-        L.orc_pnorm.restype = C.c_double
-        L.orc_pnorm.argtypes = [C.c_double, C.c_int]
-        L.orc_saddle_prob_fast.restype = C.c_double
-        L.orc_saddle_prob_fast.argtypes = [
-            C.c_double, C.c_double, C.c_double, C.c_size_t, dp, dp, C.c_size_t,
-            C.POINTER(C.c_int), C.c_double, C.POINTER(C.c_int), dp, dp, C.POINTER(OracleTrace)]
-        _lib = L
+        _lib = _bind(C.CDLL(_SO))
     return _lib
+
+
+def _bind(L):
+    dp = C.POINTER(C.c_double)
+    L.orc_model_new.restype = C.c_void_p
+    L.orc_model_new.argtypes = [C.c_int, C.c_int, C.c_int] + [dp] * 11 + [C.c_double] * 5
+    L.orc_model_free.argtypes = [C.c_void_p]
+    for nm in ("orc_scan_f64", "orc_scan_u8"):
+        f = getattr(L, nm)
+        f.restype = C.c_int
+        f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, dp, C.POINTER(C.c_uint8),
+                      C.POINTER(OracleTrace)]
+    L.orc_scan_2bit.restype = C.c_int
+    L.orc_scan_2bit.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, dp,
+                                C.POINTER(C.c_uint8), C.POINTER(OracleTrace)]
+    for nm in ("orc_pchisq1_upper", "orc_qnorm"):
+        getattr(L, nm).restype = C.c_double
+        getattr(L, nm).argtypes = [C.c_double]
+    L.orc_pnorm.restype = C.c_double
+    L.orc_pnorm.argtypes = [C.c_double, C.c_int]
+    L.orc_saddle_prob_fast.restype = C.c_double
+    L.orc_saddle_prob_fast.argtypes = [
+        C.c_double, C.c_double, C.c_double, C.c_size_t, dp, dp, C.c_size_t,
+        C.POINTER(C.c_int), C.c_double, C.POINTER(C.c_int), dp, dp, C.POINTER(OracleTrace)]
+    return L
 
 
 def _dp(a):
@@ -93,8 +105,8 @@ def saddle_prob_fast(q, m1, var1, mu, g, nonzero_idx, cutoff=2.0):
 class Oracle:
     """One flattened model (fields of saigegds_amd.nullmod.ScanModel)."""
 
-    def __init__(self, sm):
-        L = _load()
+    def __init__(self, sm, long_double: bool = False):
+        L = _load(long_double)
         self._L = L
         self.n, self.k = sm.n, sm.k
         keep = [np.ascontiguousarray(a, dtype=np.float64) for a in (

@@ -38,6 +38,13 @@
 
 #include "saige_oracle.h"
 
+/* Accumulator type of every sum.  The oracle proper uses double (as the
+ * reference); tests also build a long-double twin (liboracle_ld.so) to tell
+ * the reference's own rounding noise from a real discrepancy. */
+#ifndef ORC_ACC
+#define ORC_ACC double
+#endif
+
 /* ------------------------------------------------------------------ */
 /* Rmath stand-ins                                                      */
 
@@ -118,7 +125,7 @@ double orc_qnorm(double p)
 static void f64_af_ac_impute(double *ds, size_t n, double *AF, double *AC,
 	int *Num, int *buf_idx)
 {
-	double sum = 0;
+	ORC_ACC sum = 0;
 	int num = 0, *pIdx = buf_idx;
 	for (size_t i = 0; i < n; i++) {
 		if (isfinite(ds[i])) { sum += ds[i]; num++; }
@@ -144,25 +151,27 @@ static size_t f64_nonzero_index(size_t n, const double *x, int *idx)
 /* vectorization.cpp:309-406: p = X(m x n, column = sample) * y, skipping y==0 */
 static void f64_mul_mat_vec(size_t n, size_t m, const double *x, const double *y, double *p)
 {
-	memset(p, 0, sizeof(double) * m);
+	ORC_ACC acc[64] = {0};
 	for (size_t k = 0; k < n; k++, x += m) {
 		double alpha = y[k];
 		if (alpha != 0)
-			for (size_t i = 0; i < m; i++) p[i] += alpha * x[i];
+			for (size_t i = 0; i < m; i++) acc[i] += alpha * x[i];
 	}
+	for (size_t i = 0; i < m; i++) p[i] = (double)acc[i];
 }
 
 /* vectorization.cpp:410-499 */
 static void f64_mul_mat_vec_sp(size_t n_idx, const int *idx, size_t m,
 	const double *x, const double *y, double *p)
 {
-	memset(p, 0, sizeof(double) * m);
+	ORC_ACC acc[64] = {0};
 	for (size_t k = 0; k < n_idx; k++) {
 		size_t i = (size_t)idx[k];
 		double alpha = y[i];
 		const double *xx = &x[m * i];
-		for (size_t j = 0; j < m; j++) p[j] += alpha * xx[j];
+		for (size_t j = 0; j < m; j++) acc[j] += alpha * xx[j];
 	}
+	for (size_t j = 0; j < m; j++) p[j] = (double)acc[j];
 }
 
 /* vectorization.cpp:503-514 */
@@ -172,7 +181,7 @@ static void f64_mul_mat_vec_sub(size_t n, const int *idx, size_t m,
 	for (size_t i = 0; i < n; i++) {
 		size_t k = (size_t)idx[i];
 		const double *xx = &x[m * k];
-		double sum = 0;
+		ORC_ACC sum = 0;
 		for (size_t j = 0; j < m; j++) sum += y[j] * xx[j];
 		p[i] = sum;
 	}
@@ -183,7 +192,7 @@ static void f64_sub_mul_mat_vec(size_t n, size_t m, const double *x,
 	const double *y, const double *z, double *p)
 {
 	for (size_t i = 0; i < n; i++, y += m) {
-		double sum = 0;
+		ORC_ACC sum = 0;
 		for (size_t j = 0; j < m; j++) sum += y[j] * z[j];
 		p[i] = x[i] - sum;
 	}
@@ -192,7 +201,7 @@ static void f64_sub_mul_mat_vec(size_t n, size_t m, const double *x,
 /* vectorization.cpp:571-582 */
 static double f64_sum_mat_vec(size_t n, const double *x, const double *y)
 {
-	double sum = 0;
+	ORC_ACC sum = 0;
 	for (size_t i = 0; i < n; i++) {
 		const double *xx = &x[n * i], a = y[i];
 		for (size_t j = 0; j < n; j++) sum += a * y[j] * xx[j];
@@ -206,7 +215,7 @@ static double f64_sum_mat_vec(size_t n, const double *x, const double *y)
 /* SPATest.cpp:42-52 */
 static double Korg(double t, size_t n_g, const double mu[], const double g[])
 {
-	double sum = 0;
+	ORC_ACC sum = 0;
 	for (size_t i = 0; i < n_g; i++) {
 		double m_i = mu[i];
 		sum += log(1 - m_i + m_i * exp(g[i] * t));
@@ -217,7 +226,7 @@ static double Korg(double t, size_t n_g, const double mu[], const double g[])
 /* SPATest.cpp:56-67 */
 static double K1_adj(double t, size_t n_g, const double mu[], const double g[], double q)
 {
-	double sum = 0;
+	ORC_ACC sum = 0;
 	for (size_t i = 0; i < n_g; i++) {
 		double m_i = mu[i], g_i = g[i];
 		sum += m_i * g_i / ((1 - m_i) * exp(-g_i * t) + m_i);
@@ -228,7 +237,7 @@ static double K1_adj(double t, size_t n_g, const double mu[], const double g[], 
 /* SPATest.cpp:71-83 */
 static double K2(double t, size_t n_g, const double mu[], const double g[])
 {
-	double sum = 0;
+	ORC_ACC sum = 0;
 	for (size_t i = 0; i < n_g; i++) {
 		double m_i = mu[i], one_m_i = 1 - m_i;
 		double g_i = g[i], exp_i = exp(-g_i * t);
@@ -310,8 +319,8 @@ double orc_saddle_prob_fast(double q, double m1, double var1, size_t n_g,
 	double qinv = -s + m1;
 	double pval_noadj = orc_pchisq1_upper(s * s / var1);
 	double pval;
-	double NAmu = 0, NAsigma = 0;
-	double g_pos = 0, g_neg = 0;
+	ORC_ACC NAmu = 0, NAsigma = 0;
+	ORC_ACC g_pos = 0, g_neg = 0;
 	int init = 0;
 
 	if (p_noadj) *p_noadj = pval_noadj;
@@ -453,13 +462,13 @@ static int single_test_quant(orc_model *M, double G[], double out[6])
 		f64_mul_mat_vec_sp(nnz, idx, K, M->t_XVX_inv_XV, G, M->buf_coeff);
 		f64_mul_mat_vec_sub(nnz, idx, K, M->t_X, M->buf_coeff, M->buf_B);
 		for (size_t i = 0; i < nnz; i++) M->buf_g_tilde[i] = G[idx[i]] - M->buf_B[i];
-		double var2 = f64_sum_mat_vec(K, M->XVX, M->buf_coeff);
+		ORC_ACC var2 = f64_sum_mat_vec(K, M->XVX, M->buf_coeff);
 		for (size_t i = 0; i < nnz; i++) var2 += sq(M->buf_g_tilde[i]) - sq(M->buf_B[i]);
 		double var1 = var2 * inv_mac * M->var_ratio;
-		double S1 = 0;
+		ORC_ACC S1 = 0;
 		for (size_t i = 0; i < nnz; i++) S1 += M->y_mu[idx[i]] * M->buf_g_tilde[i];
 		f64_mul_mat_vec_sp(nnz, idx, K, M->t_X, M->y_mu, M->buf_X1);
-		double S2 = 0;
+		ORC_ACC S2 = 0;
 		for (size_t i = 0; i < K; i++) S2 += (M->buf_X1[i] - M->S_a[i]) * M->buf_coeff[i];
 		double Tstat = (S1 + S2) * inv_sqrt_mac / M->tau[0];
 		pval = orc_pchisq1_upper(Tstat * Tstat / var1);
@@ -467,7 +476,7 @@ static int single_test_quant(orc_model *M, double G[], double out[6])
 	} else {
 		f64_mul_mat_vec(n, K, M->XV, G, M->buf_coeff);
 		f64_sub_mul_mat_vec(n, K, G, M->t_XXVX_inv, M->buf_coeff, M->buf_adj_g);
-		double S = 0, var = 0;  /* f64_dot_sp, vectorization.cpp:281-291 */
+		ORC_ACC S = 0, var = 0;  /* f64_dot_sp, vectorization.cpp:281-291 */
 		for (size_t i = 0; i < n; i++) {
 			S += M->y_mu[i] * M->buf_adj_g[i];
 			var += M->buf_adj_g[i] * M->buf_adj_g[i];
@@ -507,14 +516,14 @@ static int single_test_bin(orc_model *M, double G[], double out[8], orc_trace *t
 		f64_mul_mat_vec_sp(nnz, idx, K, M->t_XVX_inv_XV, G, M->buf_coeff);
 		f64_mul_mat_vec_sub(nnz, idx, K, M->t_X, M->buf_coeff, M->buf_B);
 		for (size_t i = 0; i < nnz; i++) M->buf_g_tilde[i] = G[idx[i]] - M->buf_B[i];
-		double var2 = f64_sum_mat_vec(K, M->XVX, M->buf_coeff);
+		ORC_ACC var2 = f64_sum_mat_vec(K, M->XVX, M->buf_coeff);
 		for (size_t i = 0; i < nnz; i++)
 			var2 += (sq(M->buf_g_tilde[i]) - sq(M->buf_B[i])) * M->mu2[idx[i]];
 		double var1 = var2 * M->var_ratio;
-		double S1 = 0;
+		ORC_ACC S1 = 0;
 		for (size_t i = 0; i < nnz; i++) S1 += M->y_mu[idx[i]] * M->buf_g_tilde[i];
 		f64_mul_mat_vec_sp(nnz, idx, K, M->t_X, M->y_mu, M->buf_X1);
-		double S2 = 0;
+		ORC_ACC S2 = 0;
 		for (size_t i = 0; i < K; i++) S2 += (M->buf_X1[i] - M->S_a[i]) * M->buf_coeff[i];
 		double S = S1 + S2;
 		pval_noadj = orc_pchisq1_upper(S * S / var1);
@@ -523,7 +532,7 @@ static int single_test_bin(orc_model *M, double G[], double out[8], orc_trace *t
 	} else {
 		f64_mul_mat_vec(n, K, M->XV, G, M->buf_coeff);
 		f64_sub_mul_mat_vec(n, K, G, M->t_XXVX_inv, M->buf_coeff, M->buf_adj_g);
-		double S = 0, var = 0;  /* f64_dot_sp2, vectorization.cpp:295-305 */
+		ORC_ACC S = 0, var = 0;  /* f64_dot_sp2, vectorization.cpp:295-305 */
 		for (size_t i = 0; i < n; i++) {
 			S += M->y_mu[i] * M->buf_adj_g[i];
 			var += M->mu2[i] * M->buf_adj_g[i] * M->buf_adj_g[i];
@@ -545,9 +554,9 @@ static int single_test_bin(orc_model *M, double G[], double out[8], orc_trace *t
 		double AC2 = minus ? (2 * Num - AC) : AC;
 		double sc = 1 / sqrt(AC2);
 		for (size_t i = 0; i < n; i++) M->buf_adj_g[i] *= sc;       /* f64_mul */
-		double q = 0;
+		ORC_ACC q = 0;
 		for (size_t i = 0; i < n; i++) q += M->y[i] * M->buf_adj_g[i];  /* f64_dot */
-		double m1 = 0, var2 = 0;
+		ORC_ACC m1 = 0, var2 = 0;
 		for (size_t i = 0; i < n; i++) {                              /* f64_dot_sp2 */
 			m1 += M->mu[i] * M->buf_adj_g[i];
 			var2 += M->mu2[i] * M->buf_adj_g[i] * M->buf_adj_g[i];

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libsaigehip.so")
 EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
     "sgx_set_thresholds", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64",
-    "sgx_sync", "sgx_get_stats", "sgx_row_stride", "sgx_synth_2bit_dev",
+    "sgx_sync", "sgx_get_stats", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest",
 )
 
 
@@ -86,6 +86,8 @@ def load():
     L.sgx_version.restype = C.c_char_p
     L.sgx_last_error.restype = C.c_char_p
     L.sgx_device_count.restype = C.c_int
+    L.sgx_selftest.restype = C.c_int
+    L.sgx_selftest.argtypes = [C.c_int]
     L.sgx_init.restype = C.c_int
     L.sgx_init.argtypes = [C.POINTER(SgxModel), C.c_int, C.POINTER(vp)]
     L.sgx_free.restype = None

@@ -18,6 +18,8 @@
 
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <cmath>
+#include <algorithm>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -57,6 +59,7 @@ static int fail(int code, const char *fmt, ...)
 
 #include "dev_common.h"
 #include "kern_score.h"
+#include "kern_score_mfma.h"
 #include "kern_spa.h"
 #include "kern_spa2.h"
 #include "kern_synth.h"
@@ -72,6 +75,13 @@ struct sgx_handle {
 	// per-call workspace
 	SpaRec *recs = nullptr; size_t recs_cap = 0;
 	int *fallback = nullptr;          // rec indices that need the exact dense pass
+	// exact-integer MFMA score path (kern_score_mfma.h)
+	bool mf_ok = false;
+	MfTab mf{};
+	uint8_t *dFl = nullptr; unsigned long long *dFq = nullptr;
+	int *mf_acc = nullptr; unsigned long long *mf_t3lo = nullptr; long long *mf_t3hi = nullptr;
+	int *mf_n3 = nullptr; size_t mf_cap = 0;
+	int n_cu = 256;
 	int *counters = nullptr;          // [0] n_spa, [1] n_valid, [2] n_fallback
 	int *h_counters = nullptr;        // pinned
 	double *scratch = nullptr; size_t scratch_stride = 0; int spa_grid = 0;
@@ -80,6 +90,7 @@ struct sgx_handle {
 	double *stage_out = nullptr; uint8_t *stage_valid = nullptr; size_t stage_out_cap = 0;
 	hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 	sgx_stats stats{};
+	bool force_v1 = false;            // SAIGEHIP_SCORE_V1=1: gather kernel instead of the MFMA path
 	bool stats_pending = false;
 };
 
@@ -169,6 +180,50 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		f[2 * K] = m->y_mu[i];
 		f[2 * K + 1] = w;
 	}
+	// fixed-point limb tables for the MFMA score path (binary and quantitative alike)
+	std::vector<int8_t> Fl;
+	std::vector<unsigned long long> Fq;
+	if (P <= MF_MAXP && (double)N * 384.0 < 2147483647.0) {
+		MfTab &tb = h->mf;
+		const int ncolv = MF_NLIMB * P + 1;
+		tb.nbfv = (ncolv + 15) / 16;
+		tb.ncol = 16 * (tb.nbfv + 1);
+		tb.col_ones = MF_NLIMB * P;
+		tb.col_b1 = 16 * tb.nbfv;
+		const int ngrp = (N + 15) / 16;
+		tb.ntile = (ngrp + 15) / 16;
+		const size_t ngrp_pad = (size_t)tb.ntile * 16;
+		Fl.assign(ngrp_pad * tb.ncol * 16, 0);
+		Fq.assign((size_t)N * P, 0);
+		for (int c = 0; c < P; c++) {
+			double mx = 0;
+			for (int i = 0; i < N; i++) mx = std::max(mx, std::fabs(F[(size_t)i * P + c]));
+			int ex = 0;
+			if (mx > 0) (void)std::frexp(mx, &ex);
+			tb.escale[c] = 54 - ex;
+			__int128 tot = 0;
+			for (int i = 0; i < N; i++) {
+				long long q = std::llrint(std::ldexp(F[(size_t)i * P + c], tb.escale[c]));
+				Fq[(size_t)i * P + c] = (unsigned long long)q;
+				tot += q;
+				int8_t *base = &Fl[((size_t)(i / 16) * tb.ncol) * 16 + (i % 16)];
+				long long rem = q;
+				for (int l = 0; l < MF_NLIMB; l++) {
+					long long d = (l < MF_NLIMB - 1) ? (((rem + 128) & 255) - 128) : rem;
+					rem = (rem - d) >> 8;
+					base[(size_t)(c * MF_NLIMB + l) * 16] = (int8_t)d;
+					if (c == P - 1) base[(size_t)(tb.col_b1 + l) * 16] = (int8_t)d;
+				}
+			}
+			const __int128 two32 = ((__int128)1) << 32;
+			__int128 hi = tot / two32, lo = tot - hi * two32;
+			if (lo < 0) { lo += two32; hi -= 1; }
+			tb.ftot_hi[c] = (long long)hi; tb.ftot_lo[c] = (long long)lo;
+		}
+		for (int i = 0; i < N; i++)
+			Fl[((size_t)(i / 16) * tb.ncol + tb.col_ones) * 16 + (i % 16)] = 1;
+		h->mf_ok = true;
+	}
 	DevModel &md = h->md;
 	md.N = N; md.K = K; md.P = P; md.quant = quant;
 	md.tau0 = m->tau[0]; md.r = m->var_ratio;
@@ -182,6 +237,12 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 	TRY(dev_upload(&h->dmu, mu));
 	TRY(dev_upload(&h->dmu2, mu2));
 	TRY(dev_upload(&h->dXM, XM));
+	if (h->mf_ok) {
+		std::vector<uint8_t> Flu(Fl.begin(), Fl.end());
+		TRY(dev_upload(&h->dFl, Flu));
+		TRY(dev_upload(&h->dFq, Fq));
+		h->mf.Fl = h->dFl; h->mf.Fq = h->dFq;
+	}
 	md.F = h->dF; md.X = h->dX; md.y = h->dy; md.mu = h->dmu; md.mu2 = h->dmu2; md.XM = h->dXM;
 	hipError_t e;
 #define TRYH(x) do { e = (x); if (e != hipSuccess) { sgx_free(h); return fail(SGX_EHIP, "%s: %s", #x, hipGetErrorString(e)); } } while (0)
@@ -193,10 +254,12 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 	hipDeviceProp_t prop;
 	TRYH(hipGetDeviceProperties(&prop, device));
 	h->spa_grid = prop.multiProcessorCount * 4;
+	h->n_cu = prop.multiProcessorCount;
 	h->scratch_stride = 2 * (((size_t)N + 63) & ~(size_t)63);
 	TRYH(hipMalloc((void **)&h->scratch, h->scratch_stride * sizeof(double) * h->spa_grid));
 #undef TRY
 #undef TRYH
+	{ const char *e = getenv("SAIGEHIP_SCORE_V1"); h->force_v1 = e && e[0] == '1'; }
 	*out = h;
 	return SGX_OK;
 }
@@ -208,6 +271,8 @@ extern "C" void sgx_free(sgx_handle *h)
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
 	(void)hipFree(h->dF); (void)hipFree(h->dX); (void)hipFree(h->dy);
 	(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->fallback);
+	(void)hipFree(h->dFl); (void)hipFree(h->dFq); (void)hipFree(h->mf_acc);
+	(void)hipFree(h->mf_t3lo); (void)hipFree(h->mf_t3hi); (void)hipFree(h->mf_n3);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
 	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
@@ -225,6 +290,17 @@ static int ensure_recs(sgx_handle *h, size_t n)
 	h->recs = nullptr; h->fallback = nullptr; h->recs_cap = 0;
 	HIPCHK(hipMalloc((void **)&h->recs, n * sizeof(SpaRec)));
 	HIPCHK(hipMalloc((void **)&h->fallback, n * sizeof(int)));
+	if (h->mf_ok) {
+		if (h->mf_acc) HIPCHK(hipFree(h->mf_acc));
+		if (h->mf_t3lo) HIPCHK(hipFree(h->mf_t3lo));
+		if (h->mf_t3hi) HIPCHK(hipFree(h->mf_t3hi));
+		if (h->mf_n3) HIPCHK(hipFree(h->mf_n3));
+		h->mf_acc = nullptr; h->mf_t3lo = nullptr; h->mf_t3hi = nullptr; h->mf_n3 = nullptr;
+		HIPCHK(hipMalloc((void **)&h->mf_acc, n * (size_t)h->mf.ncol * sizeof(int)));
+		HIPCHK(hipMalloc((void **)&h->mf_t3lo, n * (size_t)h->md.P * sizeof(long long)));
+		HIPCHK(hipMalloc((void **)&h->mf_t3hi, n * (size_t)h->md.P * sizeof(long long)));
+		HIPCHK(hipMalloc((void **)&h->mf_n3, n * sizeof(int)));
+	}
 	h->recs_cap = n;
 	return SGX_OK;
 }
@@ -242,27 +318,61 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	hipStream_t st = h->stream;
 	HIPCHK(hipMemsetAsync(h->counters, 0, 4 * sizeof(int), st));
 	HIPCHK(hipEventRecord(h->ev[0], st));
+	const bool use_mf = (INPUT == IN_2BIT) && h->mf_ok && !h->force_v1;
+	if (use_mf) {
+		const MfTab &tb = h->mf;
+		const int P = md.P;
+		HIPCHK(hipMemsetAsync(h->mf_acc, 0, M * (size_t)tb.ncol * sizeof(int), st));
+		HIPCHK(hipMemsetAsync(h->mf_t3lo, 0, M * (size_t)P * sizeof(long long), st));
+		HIPCHK(hipMemsetAsync(h->mf_t3hi, 0, M * (size_t)P * sizeof(long long), st));
+		HIPCHK(hipMemsetAsync(h->mf_n3, 0, M * sizeof(int), st));
+		const int vt = (int)((M + MF_VPB - 1) / MF_VPB);
+		// split the samples so that the grid is a few rounds of 2 workgroups per CU
+		int sk = std::max(1, (h->n_cu * 2 * 4 + vt / 2) / vt);
+		sk = std::min(sk, tb.ntile);
+		const int tps = (tb.ntile + sk - 1) / sk;
+		sk = (tb.ntile + tps - 1) / tps;
+		const dim3 mgrid((unsigned)vt, (unsigned)sk);
+		const size_t lds = (size_t)16 * tb.ncol * 16 + (size_t)MF_WAVES * MF_VPW * P * 16 +
+			(size_t)MF_WAVES * MF_VPW * 4 + (size_t)MF_WAVES * MF_QCAP * 4;
+#define MFCASE(NB, PP)                                                                        \
+	hipLaunchKernelGGL((score_mfma_kernel<NB, PP>), mgrid, dim3(WAVE * MF_WAVES), lds, st,      \
+		(const uint8_t *)rows, row_bytes, (int)M, md.N, tb, tps, h->mf_acc, h->mf_t3lo,        \
+		h->mf_t3hi, h->mf_n3);                                                                 \
+	hipLaunchKernelGGL((score_mfma_epilogue<PP>), dim3((unsigned)((M + 255) / 256)), dim3(256), \
+		0, st, (int)M, md, tb, h->mf_acc, h->mf_t3lo, h->mf_t3hi, h->mf_n3, h->recs,           \
+		h->counters, out8, valid);
+		switch (P) {
+		case 4: MFCASE(2, 4) break;
+		case 6: MFCASE(3, 6) break;
+		case 8: MFCASE(4, 8) break;
+		case 10: MFCASE(5, 10) break;
+		default: return fail(SGX_EINVAL, "MFMA score path: unsupported P=%d", P);
+		}
+#undef MFCASE
+	} else {
 	const dim3 grid((unsigned)M);
-	switch (md.K) {
-#define CASE(KK)                                                                             \
-	case KK:                                                                                 \
-		if (INPUT == IN_2BIT)                                                                \
-			hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, SB>), grid, dim3(SB), 0, st,     \
-				(const uint8_t *)rows, row_bytes, (int)M, md, h->recs, h->counters, out8, valid); \
-		else if (INPUT == IN_U8)                                                             \
-			hipLaunchKernelGGL((score_ds_kernel<2 * KK + 2, SB, uint8_t>), grid, dim3(SB), 0, st, \
-				(const uint8_t *)rows, (int)M, md, h->recs, h->counters, out8, valid);      \
-		else                                                                                 \
-			hipLaunchKernelGGL((score_ds_kernel<2 * KK + 2, SB, double>), grid, dim3(SB), 0, st, \
-				(const double *)rows, (int)M, md, h->recs, h->counters, out8, valid);       \
-		break;
-		FOR_EACH_K(CASE)
-#undef CASE
-	default: return fail(SGX_EINVAL, "unsupported K=%d", md.K);
+		switch (md.K) {
+	#define CASE(KK)                                                                             \
+		case KK:                                                                                 \
+			if (INPUT == IN_2BIT)                                                                \
+				hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, SB>), grid, dim3(SB), 0, st,     \
+					(const uint8_t *)rows, row_bytes, (int)M, md, h->recs, h->counters, out8, valid); \
+			else if (INPUT == IN_U8)                                                             \
+				hipLaunchKernelGGL((score_ds_kernel<2 * KK + 2, SB, uint8_t>), grid, dim3(SB), 0, st, \
+					(const uint8_t *)rows, (int)M, md, h->recs, h->counters, out8, valid);      \
+			else                                                                                 \
+				hipLaunchKernelGGL((score_ds_kernel<2 * KK + 2, SB, double>), grid, dim3(SB), 0, st, \
+					(const double *)rows, (int)M, md, h->recs, h->counters, out8, valid);       \
+			break;
+			FOR_EACH_K(CASE)
+	#undef CASE
+		default: return fail(SGX_EINVAL, "unsupported K=%d", md.K);
+		}
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[1], st));
-	h->stats.score_launches = 1;
+	h->stats.score_launches = use_mf ? 2 : 1;
 	h->stats.spa_launches = 0;
 	if (!md.quant) {
 		const dim3 sgrid((unsigned)std::min<size_t>(M, (size_t)h->spa_grid));
@@ -446,5 +556,31 @@ extern "C" int sgx_synth_2bit_dev(sgx_handle *h, uint8_t *packed_dev, size_t bpv
 			bpv, (int)n_samp, m, first_variant + off, seed, thr_dev + 3 * off);
 		HIPCHK(hipGetLastError());
 	}
+	return SGX_OK;
+}
+
+// Checks the operand/result lane maps of v_mfma_i32_16x16x64_i8 that the MFMA
+// score path relies on, with asymmetric integer data.
+extern "C" int sgx_selftest(int device)
+{
+	HIPCHK(hipSetDevice(device));
+	std::vector<int8_t> A(16 * 64), B(64 * 16);
+	std::vector<int> D(256), R(256, 0);
+	uint64_t x = 12345;
+	for (auto &v : A) { x = splitmix64(x); v = (int8_t)(x & 3); }
+	for (auto &v : B) { x = splitmix64(x); v = (int8_t)(x & 0xFF); }
+	for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) for (int k = 0; k < 64; k++)
+		R[i * 16 + j] += (int)A[i * 64 + k] * (int)B[k * 16 + j];
+	int8_t *dA, *dB; int *dD;
+	HIPCHK(hipMalloc((void **)&dA, A.size())); HIPCHK(hipMalloc((void **)&dB, B.size()));
+	HIPCHK(hipMalloc((void **)&dD, 256 * sizeof(int)));
+	HIPCHK(hipMemcpy(dA, A.data(), A.size(), hipMemcpyHostToDevice));
+	HIPCHK(hipMemcpy(dB, B.data(), B.size(), hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, 0, dA, dB, dD);
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(D.data(), dD, 256 * sizeof(int), hipMemcpyDeviceToHost));
+	(void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
+	for (int i = 0; i < 256; i++)
+		if (D[i] != R[i]) return fail(SGX_EHIP, "sgx_selftest: MFMA i8 lane map mismatch at %d: %d != %d", i, D[i], R[i]);
 	return SGX_OK;
 }

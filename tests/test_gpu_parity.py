@@ -176,3 +176,9 @@ def test_seqAssocGLMM_SPA_driver(grm1k, golden_bin, tmp_path):
     keep = golden_bin["mac"] >= 40
     assert 0 < keep.sum() < 10000 and np.array_equal(np.asarray(r["id"]), golden_bin["id"][keep])
     assert np.max(np.abs(np.asarray(r["pval"]) / golden_bin["pval"][keep] - 1)) <= 1e-10
+
+
+def test_mfma_lane_map_selftest():
+    """v_mfma_i32_16x16x64_i8 operand/result lane maps assumed by the score kernel."""
+    from saigegds_amd import _lib
+    _lib.check(_lib.load().sgx_selftest(0))
