@@ -92,6 +92,7 @@ typedef struct sgx_stats {
 	uint64_t n_valid;      /* passed the filter                               */
 	uint64_t n_spa;        /* pval_noadj <= spa.pval, handed to the SPA stage */
 	uint64_t n_spa_dense;  /* of those, needed the exact dense g_pos/g_neg pass */
+	uint64_t n_spa_slow;   /* of those, finished by the per-workgroup kernel    */
 	float ms_score;        /* HIP-event time of the score kernel(s), ms       */
 	float ms_spa;          /* HIP-event time of the SPA kernel(s), ms         */
 	float ms_total;        /* first launch .. last launch complete, ms        */

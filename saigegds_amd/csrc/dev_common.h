@@ -25,6 +25,8 @@ struct DevModel {
 struct SpaRec {
 	int j;            // variant index in the block
 	int minus;        // AF > 0.5
+	int nnz;          // carriers: samples whose (imputed, flipped) dosage is non-zero
+	int pad_;
 	double lut[4];    // dosage value per 2-bit code after impute + flip
 	double AC2;       // allele count of the tested (minor) allele
 	double p_noadj;

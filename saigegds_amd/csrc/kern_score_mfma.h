@@ -53,7 +53,7 @@ struct MfTab {
 	long long ftot_lo[MF_MAXP];
 };
 
-// 16 two-bit codes -> 16 bytes (value plane) and their bit 1 (0/1 bytes)
+// 16 two-bit codes -> 16 bytes (value plane) and twice their bit 1 (0/2 bytes)
 __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 {
 #pragma unroll
@@ -62,7 +62,7 @@ __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 		const uint32_t y = (t | (t << 12)) & 0x000F000Fu;
 		const uint32_t z = (y | (y << 6)) & 0x03030303u;
 		val[k] = (int)z;
-		b1[k] = (int)((z >> 1) & 0x01010101u);
+		b1[k] = (int)(z & 0x02020202u);   // bit 1 kept in place: the plane is 2*[code>=2]
 	}
 }
 
@@ -88,7 +88,7 @@ __device__ __forceinline__ void mf_flush_missing(int cnt, const uint32_t *q, con
 
 // grid = (variant tiles of MF_VPB, sample splits); block = 64 * MF_WAVES
 template <int NBFV, int P>
-__global__ void __launch_bounds__(WAVE * MF_WAVES)
+__global__ void __launch_bounds__(WAVE * MF_WAVES, 2)
 score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, int N, MfTab tb,
 	int tiles_per_split, int *__restrict__ accbuf, unsigned long long *__restrict__ t3g_lo,
 	long long *__restrict__ t3g_hi, int *__restrict__ n3g)
@@ -97,8 +97,8 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, int N, 
 	constexpr int NCOL = 16 * NBF;
 	constexpr int TILE_BYTES = 16 * NCOL * 16;
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	uint8_t *ldsB = smem;                                              // TILE_BYTES
-	unsigned long long *t3lo = reinterpret_cast<unsigned long long *>(smem + TILE_BYTES);   // [WAVES][64][P]
+	uint8_t *ldsB = smem;                                              // 2 x TILE_BYTES (double buffer)
+	unsigned long long *t3lo = reinterpret_cast<unsigned long long *>(smem + 2 * TILE_BYTES);   // [WAVES][64][P]
 	long long *t3hi = reinterpret_cast<long long *>(t3lo + MF_WAVES * MF_VPW * P);
 	int *n3 = reinterpret_cast<int *>(t3hi + MF_WAVES * MF_VPW * P);   // [WAVES][64]
 	uint32_t *mq = reinterpret_cast<uint32_t *>(n3 + MF_WAVES * MF_VPW);   // [WAVES][QCAP]
@@ -132,32 +132,42 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, int N, 
 		rowp[f] = packed + (size_t)(vok[f] ? v : 0) * bpv;
 	}
 
-	for (int t = t0; t < t1; t++) {
-		// this lane's 64 samples of each of its 4 variants: dwords 16t+4kg .. +3
+	// B tile t -> LDS buffer (t & 1) by LDS-DMA: 1 KiB per wave-instruction, lane-linear
+	auto issue_B = [&](int t) {
+		const uint8_t *src = tb.Fl + (size_t)t * TILE_BYTES;
+		uint8_t *dst = ldsB + (size_t)(t & 1) * TILE_BYTES;
+#pragma unroll
+		for (int k = wid; k < TILE_BYTES / 1024; k += MF_WAVES)
+			__builtin_amdgcn_global_load_lds(
+				(const __attribute__((address_space(1))) void *)(src + (size_t)k * 1024 + lane * 16),
+				(__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
+	};
+	// this lane's 64 samples of each of its 4 variants in tile t: dwords 16t+4kg .. +3
+	auto load_A = [&](int t, uint4 (&a)[MF_NAF]) {
 		const size_t boff = ((size_t)16 * t + 4 * kg) * 4;
-		uint4 araw[MF_NAF];
 #pragma unroll
 		for (int f = 0; f < MF_NAF; f++) {
-			araw[f] = make_uint4(0, 0, 0, 0);
-			if (vok[f] && boff + 16 <= bpv) araw[f] = *reinterpret_cast<const uint4 *>(rowp[f] + boff);
+			a[f] = make_uint4(0, 0, 0, 0);
+			if (vok[f] && boff + 16 <= bpv) a[f] = *reinterpret_cast<const uint4 *>(rowp[f] + boff);
 		}
-		__syncthreads();   // previous tile fully consumed
-		{
-			const uint4 *src = reinterpret_cast<const uint4 *>(tb.Fl + (size_t)t * TILE_BYTES);
-			uint4 *dst = reinterpret_cast<uint4 *>(ldsB);
-			for (int o = tid; o < TILE_BYTES / 16; o += WAVE * MF_WAVES) dst[o] = src[o];
-		}
-		__syncthreads();
+	};
+
+	uint4 acur[MF_NAF], anxt[MF_NAF];
+	if (t0 < t1) { load_A(t0, acur); issue_B(t0); }
+	for (int t = t0; t < t1; t++) {
+		__syncthreads();   // tile t landed (each wave drained its own DMA), tile t-1 fully consumed
+		if (t + 1 < t1) { load_A(t + 1, anxt); issue_B(t + 1); }
+		const uint8_t *bt = ldsB + (size_t)(t & 1) * TILE_BYTES;
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
 			const int g = 4 * kg + u;
 			v4i bfrag[NBF];
 #pragma unroll
 			for (int b = 0; b < NBF; b++)
-				bfrag[b] = *reinterpret_cast<const v4i *>(ldsB + ((size_t)(g * NCOL + b * 16 + r)) * 16);
+				bfrag[b] = *reinterpret_cast<const v4i *>(bt + ((size_t)(g * NCOL + b * 16 + r)) * 16);
 #pragma unroll
 			for (int f = 0; f < MF_NAF; f++) {
-				const uint32_t w = (u == 0) ? araw[f].x : (u == 1) ? araw[f].y : (u == 2) ? araw[f].z : araw[f].w;
+				const uint32_t w = (u == 0) ? acur[f].x : (u == 1) ? acur[f].y : (u == 2) ? acur[f].z : acur[f].w;
 				v4i val, b1;
 				mf_unpack(w, val, b1);
 #pragma unroll
@@ -186,6 +196,8 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, int N, 
 				}
 			}
 		}
+#pragma unroll
+		for (int f = 0; f < MF_NAF; f++) acur[f] = anxt[f];
 	}
 	mf_flush_missing<P>(qn, my_q, tb, my_lo, my_hi, my_n3, lane);
 
@@ -247,6 +259,8 @@ score_mfma_epilogue(int M, DevModel md, MfTab tb, const int *__restrict__ accbuf
 	const int n3 = n3g[j];
 	const int N = md.N;
 	const long long AC = (long long)a[tb.col_ones] - 3ll * n3;
+	const int n2 = a[tb.col_b1 + MF_NLIMB] / 2 - n3;       // bit-1 plane (0/2) against the ones column
+	const int n1 = (int)(AC - 2ll * n2);
 	const VarHead h = make_head(md, (double)AC, N - n3);
 	double *o = out8 + (size_t)j * 8;
 	if (!h.pass) { nan_row(o); valid[j] = 0; return; }
@@ -266,8 +280,8 @@ score_mfma_epilogue(int M, DevModel md, MfTab tb, const int *__restrict__ accbuf
 		if (c == P - 1) { Wm = W; T3m = T3; }
 	}
 	{   // last column carries G^2
-		const HiLo B1 = mf_limbs(a + tb.col_b1);
-		const HiLo H2 = hl(B1.hi - T3m.hi, B1.lo - T3m.lo);
+		const HiLo B2 = mf_limbs(a + tb.col_b1);          // = 2 (T2 + T3), the plane holds 0/2
+		const HiLo H2 = hl(B2.hi / 2 - T3m.hi, B2.lo / 2 - T3m.lo);   // every limb sum of that plane is even
 		const double t3d = hl_to_double(T3m);
 		double w;
 		if (!h.minus) {
@@ -286,6 +300,7 @@ score_mfma_epilogue(int M, DevModel md, MfTab tb, const int *__restrict__ accbuf
 		const int slot = atomicAdd(&counters[0], 1);
 		SpaRec rr;
 		rr.j = j; rr.minus = h.minus; rr.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
+		rr.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); rr.pad_ = 0;
 		rr.p_noadj = pn; rr.S = Ssc; rr.var2 = v2sc;
 		for (int k = 0; k < 4; k++) rr.lut[k] = h.lut[k];
 		for (int k = 0; k < KMAX; k++) rr.c[k] = (k < md.K) ? cbuf[k] : 0.0;

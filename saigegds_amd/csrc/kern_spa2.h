@@ -159,7 +159,8 @@ __device__ __forceinline__ double lugannani_rice(double t, double Ksum, double k
 template <int K, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 spa2_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md,
-	const SpaRec *__restrict__ recs, int *__restrict__ counters, int *__restrict__ fallback,
+	const SpaRec *__restrict__ recs, int *__restrict__ counters, int counter_slot,
+	const int *__restrict__ rec_index, int *__restrict__ fallback,
 	double *__restrict__ scratch, size_t scratch_stride, double *__restrict__ out8)
 {
 	constexpr int NW = BLOCK / WAVE;
@@ -169,12 +170,13 @@ spa2_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md,
 	__shared__ uint32_t qidx[BLOCK * SPA2_QCAP];
 	const int N = md.N, tid = threadIdx.x;
 	const int lane = tid & (WAVE - 1), wid = tid / WAVE;
-	const int nflag = counters[0];
+	const int nflag = counters[counter_slot];
 	double *gl = scratch + (size_t)blockIdx.x * scratch_stride;
 	double *ml = gl + scratch_stride / 2;
 	const int ndw = (N + 15) >> 4;
 
-	for (int v = blockIdx.x; v < nflag; v += gridDim.x) {
+	for (int vi = blockIdx.x; vi < nflag; vi += gridDim.x) {
+		const int v = rec_index ? rec_index[vi] : vi;
 		const SpaRec r = recs[v];
 		const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (size_t)r.j * bpv);
 		const double inv = 1 / sqrt(r.AC2);

@@ -62,6 +62,7 @@ static int fail(int code, const char *fmt, ...)
 #include "kern_score_mfma.h"
 #include "kern_spa.h"
 #include "kern_spa2.h"
+#include "kern_spa3.h"
 #include "kern_synth.h"
 
 // ---------------------------------------------------------------------------
@@ -75,6 +76,13 @@ struct sgx_handle {
 	// per-call workspace
 	SpaRec *recs = nullptr; size_t recs_cap = 0;
 	int *fallback = nullptr;          // rec indices that need the exact dense pass
+	int *fb_spa2 = nullptr;           // rec indices left to the per-workgroup SPA kernel
+	// level-synchronous SPA (kern_spa3.h)
+	SpaHead *heads = nullptr;
+	double2 *arena = nullptr; unsigned long long arena_cap = 0;
+	unsigned long long *cursor = nullptr;
+	ChunkDesc *chunks = nullptr; double4 *partial = nullptr; int chunk_cap = 0;
+	int spa_levels = 12;
 	// exact-integer MFMA score path (kern_score_mfma.h)
 	bool mf_ok = false;
 	MfTab mf{};
@@ -220,8 +228,10 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 			if (lo < 0) { lo += two32; hi -= 1; }
 			tb.ftot_hi[c] = (long long)hi; tb.ftot_lo[c] = (long long)lo;
 		}
-		for (int i = 0; i < N; i++)
+		for (int i = 0; i < N; i++) {
 			Fl[((size_t)(i / 16) * tb.ncol + tb.col_ones) * 16 + (i % 16)] = 1;
+			Fl[((size_t)(i / 16) * tb.ncol + tb.col_b1 + MF_NLIMB) * 16 + (i % 16)] = 1;
+		}
 		h->mf_ok = true;
 	}
 	DevModel &md = h->md;
@@ -247,16 +257,22 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 	hipError_t e;
 #define TRYH(x) do { e = (x); if (e != hipSuccess) { sgx_free(h); return fail(SGX_EHIP, "%s: %s", #x, hipGetErrorString(e)); } } while (0)
 	TRYH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-	TRYH(hipMalloc((void **)&h->counters, 4 * sizeof(int)));
-	TRYH(hipHostMalloc((void **)&h->h_counters, 4 * sizeof(int), hipHostMallocDefault));
+	TRYH(hipMalloc((void **)&h->counters, 8 * sizeof(int)));
+	TRYH(hipHostMalloc((void **)&h->h_counters, 8 * sizeof(int), hipHostMallocDefault));
+	TRYH(hipMalloc((void **)&h->cursor, sizeof(unsigned long long)));
 	for (int i = 0; i < 3; i++) TRYH(hipEventCreate(&h->ev[i]));
 	// SPA scratch: one (adj, mu) list of N entries per resident workgroup
 	hipDeviceProp_t prop;
 	TRYH(hipGetDeviceProperties(&prop, device));
-	h->spa_grid = prop.multiProcessorCount * 4;
+	h->spa_grid = prop.multiProcessorCount * 2;
 	h->n_cu = prop.multiProcessorCount;
 	h->scratch_stride = 2 * (((size_t)N + 63) & ~(size_t)63);
 	TRYH(hipMalloc((void **)&h->scratch, h->scratch_stride * sizeof(double) * h->spa_grid));
+	if (!quant) {
+		// arena of (adj, mu) carrier lists shared by all flagged variants of a call
+		h->arena_cap = std::min<unsigned long long>(400000000ull, std::max<unsigned long long>(4000000ull, (unsigned long long)N * 1024ull));
+		TRYH(hipMalloc((void **)&h->arena, h->arena_cap * sizeof(double2)));
+	}
 #undef TRY
 #undef TRYH
 	{ const char *e = getenv("SAIGEHIP_SCORE_V1"); h->force_v1 = e && e[0] == '1'; }
@@ -270,7 +286,8 @@ extern "C" void sgx_free(sgx_handle *h)
 	(void)hipSetDevice(h->device);
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
 	(void)hipFree(h->dF); (void)hipFree(h->dX); (void)hipFree(h->dy);
-	(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->fallback);
+	(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->fallback); (void)hipFree(h->fb_spa2); (void)hipFree(h->heads);
+	(void)hipFree(h->arena); (void)hipFree(h->cursor); (void)hipFree(h->chunks); (void)hipFree(h->partial);
 	(void)hipFree(h->dFl); (void)hipFree(h->dFq); (void)hipFree(h->mf_acc);
 	(void)hipFree(h->mf_t3lo); (void)hipFree(h->mf_t3hi); (void)hipFree(h->mf_n3);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
@@ -290,6 +307,18 @@ static int ensure_recs(sgx_handle *h, size_t n)
 	h->recs = nullptr; h->fallback = nullptr; h->recs_cap = 0;
 	HIPCHK(hipMalloc((void **)&h->recs, n * sizeof(SpaRec)));
 	HIPCHK(hipMalloc((void **)&h->fallback, n * sizeof(int)));
+	if (!h->md.quant) {
+		if (h->fb_spa2) HIPCHK(hipFree(h->fb_spa2));
+		if (h->heads) HIPCHK(hipFree(h->heads));
+		if (h->chunks) HIPCHK(hipFree(h->chunks));
+		if (h->partial) HIPCHK(hipFree(h->partial));
+		h->fb_spa2 = nullptr; h->heads = nullptr; h->chunks = nullptr; h->partial = nullptr;
+		h->chunk_cap = (int)std::min<unsigned long long>(0x7fffffffull, h->arena_cap / SPA3_CHUNK + n);
+		HIPCHK(hipMalloc((void **)&h->fb_spa2, n * sizeof(int)));
+		HIPCHK(hipMalloc((void **)&h->heads, n * sizeof(SpaHead)));
+		HIPCHK(hipMalloc((void **)&h->chunks, (size_t)h->chunk_cap * sizeof(ChunkDesc)));
+		HIPCHK(hipMalloc((void **)&h->partial, (size_t)h->chunk_cap * sizeof(double4)));
+	}
 	if (h->mf_ok) {
 		if (h->mf_acc) HIPCHK(hipFree(h->mf_acc));
 		if (h->mf_t3lo) HIPCHK(hipFree(h->mf_t3lo));
@@ -316,7 +345,8 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	const DevModel &md = h->md;
 	constexpr int SB = 256, PB = 512;
 	hipStream_t st = h->stream;
-	HIPCHK(hipMemsetAsync(h->counters, 0, 4 * sizeof(int), st));
+	HIPCHK(hipMemsetAsync(h->counters, 0, 8 * sizeof(int), st));
+	HIPCHK(hipMemsetAsync(h->cursor, 0, sizeof(unsigned long long), st));
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	const bool use_mf = (INPUT == IN_2BIT) && h->mf_ok && !h->force_v1;
 	if (use_mf) {
@@ -333,7 +363,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		const int tps = (tb.ntile + sk - 1) / sk;
 		sk = (tb.ntile + tps - 1) / tps;
 		const dim3 mgrid((unsigned)vt, (unsigned)sk);
-		const size_t lds = (size_t)16 * tb.ncol * 16 + (size_t)MF_WAVES * MF_VPW * P * 16 +
+		const size_t lds = (size_t)2 * 16 * tb.ncol * 16 + (size_t)MF_WAVES * MF_VPW * P * 16 +
 			(size_t)MF_WAVES * MF_VPW * 4 + (size_t)MF_WAVES * MF_QCAP * 4;
 #define MFCASE(NB, PP)                                                                        \
 	hipLaunchKernelGGL((score_mfma_kernel<NB, PP>), mgrid, dim3(WAVE * MF_WAVES), lds, st,      \
@@ -380,9 +410,25 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 #define CASE(KK)                                                                             \
 	case KK:                                                                                 \
 		if (INPUT == IN_2BIT) {                                                              \
+			const dim3 g256((unsigned)((M + 255) / 256));                                    \
+			const dim3 gchunk((unsigned)(h->n_cu * 8));                                      \
+			hipLaunchKernelGGL((spa3_extract<KK, PB>), sgrid, dim3(PB), 0, st,               \
+				(const uint8_t *)rows, row_bytes, md, h->recs, h->counters, h->cursor,       \
+				h->arena_cap, h->arena, h->heads, h->chunks, h->chunk_cap, h->fallback,      \
+				h->fb_spa2, out8);                                                           \
+			for (int lv = 0; lv < h->spa_levels; lv++) {                                     \
+				hipLaunchKernelGGL(spa3_pass, gchunk, dim3(SPA3_BLOCK), 0, st, h->counters,  \
+					h->chunks, h->heads, h->arena, h->partial);                              \
+				hipLaunchKernelGGL(spa3_advance, g256, dim3(256), 0, st, h->counters,        \
+					h->heads, h->partial);                                                   \
+			}                                                                                \
+			hipLaunchKernelGGL(spa3_korg, gchunk, dim3(SPA3_BLOCK), 0, st, h->counters,      \
+				h->chunks, h->heads, h->arena, h->partial);                                  \
+			hipLaunchKernelGGL(spa3_finish, g256, dim3(256), 0, st, h->counters, h->heads,   \
+				h->partial, h->recs, h->fb_spa2, out8);                                      \
 			hipLaunchKernelGGL((spa2_kernel<KK, PB>), sgrid, dim3(PB), 0, st,                \
-				(const uint8_t *)rows, row_bytes, md, h->recs, h->counters, h->fallback,     \
-				h->scratch, h->scratch_stride, out8);                                        \
+				(const uint8_t *)rows, row_bytes, md, h->recs, h->counters, 3, h->fb_spa2,   \
+				h->fallback, h->scratch, h->scratch_stride, out8);                           \
 			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
 				row_bytes, md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
 				h->scratch_stride, out8);                                                    \
@@ -396,10 +442,10 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 #undef CASE
 		}
 		HIPCHK(hipGetLastError());
-		h->stats.spa_launches = (INPUT == IN_2BIT) ? 2 : 1;
+		h->stats.spa_launches = (INPUT == IN_2BIT) ? (uint32_t)(5 + 2 * h->spa_levels) : 1u;
 	}
 	HIPCHK(hipEventRecord(h->ev[2], st));
-	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 4 * sizeof(int), hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
 	h->stats.n_variants = M;
 	h->stats_pending = true;
 	return SGX_OK;
@@ -415,6 +461,7 @@ extern "C" int sgx_sync(sgx_handle *h)
 		h->stats.n_spa = (uint64_t)h->h_counters[0];
 		h->stats.n_valid = (uint64_t)h->h_counters[1];
 		h->stats.n_spa_dense = (uint64_t)h->h_counters[2];
+		h->stats.n_spa_slow = (uint64_t)h->h_counters[3];
 		float a = 0, b = 0, c = 0;
 		(void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
 		(void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
@@ -510,7 +557,7 @@ static int scan_host(sgx_handle *h, const void *rows, size_t src_row_bytes, size
 		rc = sgx_sync(h);
 		if (rc) return rc;
 		total.n_variants += h->stats.n_variants; total.n_valid += h->stats.n_valid;
-		total.n_spa += h->stats.n_spa; total.n_spa_dense += h->stats.n_spa_dense; total.ms_score += h->stats.ms_score;
+		total.n_spa += h->stats.n_spa; total.n_spa_dense += h->stats.n_spa_dense; total.n_spa_slow += h->stats.n_spa_slow; total.ms_score += h->stats.ms_score;
 		total.ms_spa += h->stats.ms_spa; total.ms_total += h->stats.ms_total;
 		total.score_launches += h->stats.score_launches; total.spa_launches += h->stats.spa_launches;
 	}

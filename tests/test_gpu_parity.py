@@ -5,7 +5,17 @@ import pytest
 
 from conftest import assert_table_close, scan_model
 
-pytestmark = pytest.mark.gpu
+# every test here needs the GPU; a hung kernel must fail the test, not stall the run
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300, method="thread")]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _torch_first():
+    """Import torch before the first HIP call of this process: libsaigehip.so then
+    binds to the HIP runtime of the torch wheel and nothing is loaded mid-run."""
+    import torch
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    yield
 
 
 def _scanner(sm):
