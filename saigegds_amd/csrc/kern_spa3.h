@@ -8,7 +8,7 @@
 // Newton iteration of ALL flagged variants advances in lock step and each
 // level is one balanced launch over fixed-size chunks of the carrier lists:
 //
-//   spa3_extract  one workgroup per flagged variant: carrier list (adj, mu)
+//   spa3_count/plan/fill/head  carrier lists (adj, mu) of all flagged variants
 //                 appended to one global arena; scalars; cutoff exit; bound
 //                 test for g_pos/g_neg (kern_spa2.h); chunk descriptors
 //   repeat L times
@@ -52,26 +52,82 @@ __device__ __forceinline__ void spa_write_row(const SpaRec &r, double Tstat, dou
 
 // counters: [0] n_spa [1] n_valid [2] n_dense_fallback [3] n_spa2_fallback
 //           [4] chunk cursor [6] number of valid chunk descriptors
-template <int K, int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
-spa3_extract(const uint8_t *__restrict__ packed, size_t bpv, DevModel md,
-	const SpaRec *__restrict__ recs, int *__restrict__ counters, unsigned long long *__restrict__ cursor,
-	unsigned long long arena_cap, double2 *__restrict__ arena, SpaHead *__restrict__ heads,
-	ChunkDesc *__restrict__ chunks, int chunk_cap, int *__restrict__ fb_dense, int *__restrict__ fb_spa2,
-	double *__restrict__ out8)
+//
+// Extraction is split so that every launch is balanced over (variant, segment)
+// work items, a segment being SPA3_SEG consecutive samples of one flagged row:
+//   spa3_count  carriers per (variant, segment)
+//   spa3_plan   per variant: exclusive scan over its segments, arena allocation
+//   spa3_fill   per (variant, segment): gather X_i, mu_i -> (adj, mu) entries at
+//               their final position (ascending sample order), partial sums
+//   spa3_head   per variant: ordered sum of the partials, scalars, cutoff exit,
+//               g_pos/g_neg bound test, root_begin, chunk descriptors
+
+#define SPA3_SEG 8192        /* samples per extraction segment = 512 dwords */
+
+__global__ void __launch_bounds__(256)
+spa3_count(const uint8_t *__restrict__ packed, size_t bpv, int N, int nseg,
+	const SpaRec *__restrict__ recs, const int *__restrict__ counters, int *__restrict__ segcnt)
 {
-	constexpr int NW = BLOCK / WAVE;
+	__shared__ int shi[4];
+	const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	const int nitem = counters[0] * nseg;
+	const int ndw = (N + 15) >> 4;
+	for (int it = blockIdx.x; it < nitem; it += gridDim.x) {
+		const int v = it / nseg, seg = it - v * nseg;
+		const int minus = recs[v].minus;
+		const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (size_t)recs[v].j * bpv);
+		const uint32_t zx = minus ? 0xAAAAAAAAu : 0u;
+		int cnt = 0;
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
+			const int d = seg * (SPA3_SEG / 16) + 2 * tid + u;
+			const uint32_t w = (d < ndw) ? row[d] : 0u;
+			cnt += __popc(nz_fields((w ^ zx) & keep_mask(N - d * 16)));
+		}
+		cnt = wave_sum_i(cnt);
+		__syncthreads();
+		if (lane == 0) shi[wid] = cnt;
+		__syncthreads();
+		if (tid == 0) segcnt[it] = shi[0] + shi[1] + shi[2] + shi[3];
+	}
+}
+
+__global__ void __launch_bounds__(256)
+spa3_plan(int nseg, const SpaRec *__restrict__ recs, int *__restrict__ counters,
+	unsigned long long *__restrict__ cursor, unsigned long long arena_cap, int *__restrict__ segcnt,
+	SpaHead *__restrict__ heads, int *__restrict__ fb_spa2)
+{
+	const int v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= counters[0]) return;
+	int run = 0;
+	for (int s = 0; s < nseg; s++) { const int c = segcnt[v * nseg + s]; segcnt[v * nseg + s] = run; run += c; }
+	SpaHead *h = heads + v;
+	h->nnz = run; h->c0 = 0; h->nchunks = 0; h->state = 0;
+	const unsigned long long off = atomicAdd(cursor, (unsigned long long)run);
+	h->off = off;
+	if (off + (unsigned long long)run > arena_cap) {
+		h->nnz = -1;                                    // no list: the per-workgroup kernel takes it
+		fb_spa2[atomicAdd(&counters[3], 1)] = v;
+	}
+}
+
+template <int K>
+__global__ void __launch_bounds__(256)
+spa3_fill(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg,
+	const SpaRec *__restrict__ recs, const int *__restrict__ counters, const int *__restrict__ segoff,
+	const SpaHead *__restrict__ heads, double2 *__restrict__ arena, double *__restrict__ segpart)
+{
+	constexpr int BLOCK = 256, NW = BLOCK / WAVE;
 	constexpr int KP = (K + 2) & ~1;
 	__shared__ double sh[8 * NW];
 	__shared__ int shi[NW];
-	__shared__ uint32_t qidx[BLOCK * SPA2_QCAP];
-	__shared__ unsigned long long sh_off;
-	const int N = md.N, tid = threadIdx.x;
-	const int lane = tid & (WAVE - 1), wid = tid / WAVE;
-	const int nflag = counters[0];
+	__shared__ uint32_t qidx[SPA3_SEG];
+	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	const int nitem = counters[0] * nseg;
 	const int ndw = (N + 15) >> 4;
-
-	for (int v = blockIdx.x; v < nflag; v += gridDim.x) {
+	for (int it = blockIdx.x; it < nitem; it += gridDim.x) {
+		const int v = it / nseg, seg = it - v * nseg;
+		if (heads[v].nnz < 0) continue;
 		const SpaRec r = recs[v];
 		const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (size_t)r.j * bpv);
 		const double inv = 1 / sqrt(r.AC2);
@@ -79,116 +135,123 @@ spa3_extract(const uint8_t *__restrict__ packed, size_t bpv, DevModel md,
 		double c[K];
 #pragma unroll
 		for (int a = 0; a < K; a++) c[a] = r.c[a];
-
-		// arena space for this variant's list (order of allocation does not matter)
-		__syncthreads();
-		if (tid == 0) sh_off = atomicAdd(cursor, (unsigned long long)r.nnz);
-		__syncthreads();
-		const unsigned long long off = sh_off;
-		if (off + (unsigned long long)r.nnz > arena_cap) {
-			if (tid == 0) { fb_spa2[atomicAdd(&counters[3], 1)] = v; heads[v].state = 0; }
-			continue;
+		const int d0 = seg * (SPA3_SEG / 16) + 2 * tid;
+		uint32_t w[2], nz[2];
+		int cnt = 0;
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
+			w[u] = (d0 + u < ndw) ? row[d0 + u] : 0u;
+			nz[u] = nz_fields((w[u] ^ zx) & keep_mask(N - (d0 + u) * 16));
+			cnt += __popc(nz[u]);
 		}
-		double2 *lst = arena + off;
-
+		int incl = cnt;
+#pragma unroll
+		for (int o = 1; o < WAVE; o <<= 1) {
+			const int up = __shfl_up(incl, o, WAVE);
+			if (lane >= o) incl += up;
+		}
+		__syncthreads();                     // previous item's readers of shi / qidx are done
+		if (lane == WAVE - 1) shi[wid] = incl;
+		__syncthreads();
+		int wbase = 0, total = 0;
+#pragma unroll
+		for (int ww = 0; ww < NW; ww++) { if (ww < wid) wbase += shi[ww]; total += shi[ww]; }
+		int o2 = wbase + incl - cnt;
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
+			uint32_t z = nz[u];
+			while (z) {
+				const int b = __ffs(z) - 1;
+				z &= z - 1;
+				qidx[o2++] = (uint32_t)((d0 + u) * 16 + (b >> 1)) | (((w[u] >> b) & 3u) << 30);
+			}
+		}
+		__syncthreads();
+		double2 *lst = arena + heads[v].off + (unsigned long long)segoff[it];
 		double a6[6] = {0, 0, 0, 0, 0, 0};
-		int nnz = 0;
-		for (int d0 = 0; d0 < ndw; d0 += BLOCK) {
-			const int d = d0 + tid;
-			const uint32_t w = (d < ndw) ? row[d] : 0u;
-			uint32_t nz = nz_fields((w ^ zx) & keep_mask(N - d * 16));
-			const int cnt = __popc(nz);
-			int incl = cnt;
+		for (int k = tid; k < total; k += BLOCK) {
+			const uint32_t e = qidx[k];
+			const int i = (int)(e & 0x3FFFFFFFu);
+			const double G = sel4(r.lut, e >> 30);
+			const double *x = md.XM + (size_t)i * KP;
+			double xv[KP];
 #pragma unroll
-			for (int o = 1; o < WAVE; o <<= 1) {
-				const int up = __shfl_up(incl, o, WAVE);
-				if (lane >= o) incl += up;
+			for (int a = 0; a < KP; a += 2) {
+				const double2 t2 = *reinterpret_cast<const double2 *>(x + a);
+				xv[a] = t2.x; xv[a + 1] = t2.y;
 			}
-			if (lane == WAVE - 1) shi[wid] = incl;
-			__syncthreads();
-			int wbase = 0, total = 0;
+			double b = 0;
 #pragma unroll
-			for (int ww = 0; ww < NW; ww++) { if (ww < wid) wbase += shi[ww]; total += shi[ww]; }
-			int o2 = wbase + incl - cnt;
-			while (nz) {
-				const int b = __ffs(nz) - 1;
-				nz &= nz - 1;
-				qidx[o2++] = (uint32_t)(d * 16 + (b >> 1)) | (((w >> b) & 3u) << 30);
-			}
-			__syncthreads();
-			for (int k = tid; k < total; k += BLOCK) {
-				const uint32_t e = qidx[k];
-				const int i = (int)(e & 0x3FFFFFFFu);
-				const double G = sel4(r.lut, e >> 30);
-				const double *x = md.XM + (size_t)i * KP;
-				double xv[KP];
-#pragma unroll
-				for (int a = 0; a < KP; a += 2) {
-					const double2 t2 = *reinterpret_cast<const double2 *>(x + a);
-					xv[a] = t2.x; xv[a + 1] = t2.y;
-				}
-				double b = 0;
-#pragma unroll
-				for (int a = 0; a < K; a++) b = fma(xv[a], c[a], b);
-				const double mui = xv[K];
-				const double adj = (G - b) * inv;
-				if (nnz + k < r.nnz) lst[nnz + k] = make_double2(adj, mui);   // never outside the allotment
-				a6[0] = fma(mui, G, a6[0]);
-				a6[1] += b;
-				if (adj > 0) a6[2] += adj; else a6[3] += adj;
-				a6[4] = fma(adj, mui, a6[4]);
-				a6[5] = fma(adj * adj, mui * (1 - mui), a6[5]);
-			}
-			nnz += total;
-			__syncthreads();
+			for (int a = 0; a < K; a++) b = fma(xv[a], c[a], b);
+			const double mui = xv[K];
+			const double adj = (G - b) * inv;
+			lst[k] = make_double2(adj, mui);
+			a6[0] = fma(mui, G, a6[0]);
+			a6[1] += b;
+			if (adj > 0) a6[2] += adj; else a6[3] += adj;
+			a6[4] = fma(adj, mui, a6[4]);
+			a6[5] = fma(adj * adj, mui * (1 - mui), a6[5]);
 		}
 		block_sum<6, BLOCK>(a6, sh);
+		if (tid < 6) segpart[(size_t)it * 6 + tid] = a6[tid];
+	}
+}
 
-		if (tid == 0) {
-			double xmu_c = 0, xsum_c = 0;
-			for (int a = 0; a < K; a++) { xmu_c = fma(md.Xmu[a], c[a], xmu_c); xsum_c = fma(md.Xsum[a], c[a], xsum_c); }
-			SpaHead h;
-			h.nnz = nnz; h.off = off; h.c0 = 0; h.nchunks = 0;
-			h.m1 = (a6[0] - xmu_c) * inv;
-			h.Tstat = r.S * inv;
-			h.var2 = r.var2 / r.AC2;
-			h.var1 = h.var2 * md.r;
-			h.qtilde = h.Tstat / sqrt(h.var1) * sqrt(h.var2) + h.m1;
-			const double s = h.qtilde - h.m1;
-			h.qinv = -s + h.m1;
-			h.pn_in = d_pchisq1_upper(s * s / h.var2);
-			h.NAmu = h.m1 - a6[4];
-			h.NAsigma = h.var2 - a6[5];
-			h.state = 0;
-			if (nnz != r.nnz) {
-				// cannot happen (nnz comes from the same codes); keep the arena consistent anyway
+template <int K>
+__global__ void __launch_bounds__(256)
+spa3_head(DevModel md, int nseg, const SpaRec *__restrict__ recs, int *__restrict__ counters,
+	const double *__restrict__ segpart, SpaHead *__restrict__ heads, ChunkDesc *__restrict__ chunks,
+	int chunk_cap, int *__restrict__ fb_dense, int *__restrict__ fb_spa2, double *__restrict__ out8)
+{
+	const int v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= counters[0]) return;
+	SpaHead h = heads[v];
+	if (h.nnz < 0) { heads[v].nnz = 0; return; }
+	const SpaRec r = recs[v];
+	double a6[6] = {0, 0, 0, 0, 0, 0};
+	for (int s = 0; s < nseg; s++)
+#pragma unroll
+		for (int a = 0; a < 6; a++) a6[a] += segpart[((size_t)v * nseg + s) * 6 + a];
+	const double inv = 1 / sqrt(r.AC2);
+	double xmu_c = 0, xsum_c = 0;
+#pragma unroll
+	for (int a = 0; a < K; a++) { xmu_c = fma(md.Xmu[a], r.c[a], xmu_c); xsum_c = fma(md.Xsum[a], r.c[a], xsum_c); }
+	const int nnz = h.nnz;
+	h.m1 = (a6[0] - xmu_c) * inv;
+	h.Tstat = r.S * inv;
+	h.var2 = r.var2 / r.AC2;
+	h.var1 = h.var2 * md.r;
+	h.qtilde = h.Tstat / sqrt(h.var1) * sqrt(h.var2) + h.m1;
+	const double s = h.qtilde - h.m1;
+	h.qinv = -s + h.m1;
+	h.pn_in = d_pchisq1_upper(s * s / h.var2);
+	h.NAmu = h.m1 - a6[4];
+	h.NAsigma = h.var2 - a6[5];
+	h.state = 0;
+	if (fabs(h.qtilde - h.m1) / sqrt(h.var2) < 2.0) {
+		spa_write_row(r, h.Tstat, h.var1, h.pn_in, true, out8);   // SPATest.cpp:319-321
+	} else {
+		const double nb = (xsum_c - a6[1]) * inv;
+		const double L = a6[2] + fmax(-nb, 0.0), U = a6[3] + fmin(-nb, 0.0);
+		const double mar = 1e-9 * (fabs(L) + fabs(U) + fabs(h.qtilde) + fabs(h.qinv));
+		if (!(h.qtilde < L - mar && h.qtilde > U + mar && h.qinv < L - mar && h.qinv > U + mar)) {
+			fb_dense[atomicAdd(&counters[2], 1)] = v;
+		} else {
+			const int nch = (nnz + SPA3_CHUNK - 1) / SPA3_CHUNK;
+			const int c0 = atomicAdd(&counters[4], nch);
+			if (c0 < 0 || c0 + nch > chunk_cap) {
+				// table full: descriptors [c0, ..) stay unwritten and outside counters[6]
 				fb_spa2[atomicAdd(&counters[3], 1)] = v;
-			} else if (fabs(h.qtilde - h.m1) / sqrt(h.var2) < 2.0) {
-				spa_write_row(r, h.Tstat, h.var1, h.pn_in, true, out8);   // SPATest.cpp:319-321
 			} else {
-				const double nb = (xsum_c - a6[1]) * inv;
-				const double L = a6[2] + fmax(-nb, 0.0), U = a6[3] + fmin(-nb, 0.0);
-				const double mar = 1e-9 * (fabs(L) + fabs(U) + fabs(h.qtilde) + fabs(h.qinv));
-				if (!(h.qtilde < L - mar && h.qtilde > U + mar && h.qinv < L - mar && h.qinv > U + mar)) {
-					fb_dense[atomicAdd(&counters[2], 1)] = v;
-				} else {
-					const int nch = (nnz + SPA3_CHUNK - 1) / SPA3_CHUNK;
-					const int c0 = atomicAdd(&counters[4], nch);
-					if (c0 < 0 || c0 + nch > chunk_cap) {
-						// table full: descriptors [c0, ..) stay unwritten and outside counters[6]
-						fb_spa2[atomicAdd(&counters[3], 1)] = v;
-					} else {
-						atomicMax(&counters[6], c0 + nch);     // chunks the pass kernels may touch
-						h.c0 = c0; h.nchunks = nch; h.state = 1;
-						root_begin(h.s1, h.qtilde, L, U);
-						root_begin(h.s2, h.qinv, L, U);
-						for (int k = 0; k < nch; k++) { chunks[c0 + k].v = v; chunks[c0 + k].k = k; }
-					}
-				}
+				atomicMax(&counters[6], c0 + nch);     // chunks the pass kernels may touch
+				h.c0 = c0; h.nchunks = nch; h.state = 1;
+				root_begin(h.s1, h.qtilde, L, U);
+				root_begin(h.s2, h.qinv, L, U);
+				for (int k = 0; k < nch; k++) { chunks[c0 + k].v = v; chunks[c0 + k].k = k; }
 			}
-			heads[v] = h;
 		}
 	}
+	heads[v] = h;
 }
 
 // one workgroup per chunk; partial[chunk] = {K1(t1), K2(t1), K1(t2), K2(t2)} over its carriers

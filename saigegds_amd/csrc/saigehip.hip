@@ -82,6 +82,7 @@ struct sgx_handle {
 	double2 *arena = nullptr; unsigned long long arena_cap = 0;
 	unsigned long long *cursor = nullptr;
 	ChunkDesc *chunks = nullptr; double4 *partial = nullptr; int chunk_cap = 0;
+	int *segcnt = nullptr; double *segpart = nullptr; int nseg = 0;
 	int spa_levels = 12;
 	// exact-integer MFMA score path (kern_score_mfma.h)
 	bool mf_ok = false;
@@ -287,7 +288,7 @@ extern "C" void sgx_free(sgx_handle *h)
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
 	(void)hipFree(h->dF); (void)hipFree(h->dX); (void)hipFree(h->dy);
 	(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->fallback); (void)hipFree(h->fb_spa2); (void)hipFree(h->heads);
-	(void)hipFree(h->arena); (void)hipFree(h->cursor); (void)hipFree(h->chunks); (void)hipFree(h->partial);
+	(void)hipFree(h->arena); (void)hipFree(h->cursor); (void)hipFree(h->segcnt); (void)hipFree(h->segpart); (void)hipFree(h->chunks); (void)hipFree(h->partial);
 	(void)hipFree(h->dFl); (void)hipFree(h->dFq); (void)hipFree(h->mf_acc);
 	(void)hipFree(h->mf_t3lo); (void)hipFree(h->mf_t3hi); (void)hipFree(h->mf_n3);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
@@ -312,6 +313,12 @@ static int ensure_recs(sgx_handle *h, size_t n)
 		if (h->heads) HIPCHK(hipFree(h->heads));
 		if (h->chunks) HIPCHK(hipFree(h->chunks));
 		if (h->partial) HIPCHK(hipFree(h->partial));
+		if (h->segcnt) HIPCHK(hipFree(h->segcnt));
+		if (h->segpart) HIPCHK(hipFree(h->segpart));
+		h->segcnt = nullptr; h->segpart = nullptr;
+		h->nseg = (h->md.N + SPA3_SEG - 1) / SPA3_SEG;
+		HIPCHK(hipMalloc((void **)&h->segcnt, n * (size_t)h->nseg * sizeof(int)));
+		HIPCHK(hipMalloc((void **)&h->segpart, n * (size_t)h->nseg * 6 * sizeof(double)));
 		h->fb_spa2 = nullptr; h->heads = nullptr; h->chunks = nullptr; h->partial = nullptr;
 		h->chunk_cap = (int)std::min<unsigned long long>(0x7fffffffull, h->arena_cap / SPA3_CHUNK + n);
 		HIPCHK(hipMalloc((void **)&h->fb_spa2, n * sizeof(int)));
@@ -412,10 +419,17 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		if (INPUT == IN_2BIT) {                                                              \
 			const dim3 g256((unsigned)((M + 255) / 256));                                    \
 			const dim3 gchunk((unsigned)(h->n_cu * 8));                                      \
-			hipLaunchKernelGGL((spa3_extract<KK, PB>), sgrid, dim3(PB), 0, st,               \
-				(const uint8_t *)rows, row_bytes, md, h->recs, h->counters, h->cursor,       \
-				h->arena_cap, h->arena, h->heads, h->chunks, h->chunk_cap, h->fallback,      \
-				h->fb_spa2, out8);                                                           \
+			const dim3 gitem((unsigned)(h->n_cu * 16));                                      \
+			hipLaunchKernelGGL(spa3_count, gitem, dim3(256), 0, st, (const uint8_t *)rows,   \
+				row_bytes, md.N, h->nseg, h->recs, h->counters, h->segcnt);                  \
+			hipLaunchKernelGGL(spa3_plan, g256, dim3(256), 0, st, h->nseg, h->recs,          \
+				h->counters, h->cursor, h->arena_cap, h->segcnt, h->heads, h->fb_spa2);      \
+			hipLaunchKernelGGL((spa3_fill<KK>), gitem, dim3(256), 0, st,                     \
+				(const uint8_t *)rows, row_bytes, md, h->nseg, h->recs, h->counters,         \
+				h->segcnt, h->heads, h->arena, h->segpart);                                  \
+			hipLaunchKernelGGL((spa3_head<KK>), g256, dim3(256), 0, st, md, h->nseg,         \
+				h->recs, h->counters, h->segpart, h->heads, h->chunks, h->chunk_cap,         \
+				h->fallback, h->fb_spa2, out8);                                              \
 			for (int lv = 0; lv < h->spa_levels; lv++) {                                     \
 				hipLaunchKernelGGL(spa3_pass, gchunk, dim3(SPA3_BLOCK), 0, st, h->counters,  \
 					h->chunks, h->heads, h->arena, h->partial);                              \
@@ -442,7 +456,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 #undef CASE
 		}
 		HIPCHK(hipGetLastError());
-		h->stats.spa_launches = (INPUT == IN_2BIT) ? (uint32_t)(5 + 2 * h->spa_levels) : 1u;
+		h->stats.spa_launches = (INPUT == IN_2BIT) ? (uint32_t)(8 + 2 * h->spa_levels) : 1u;
 	}
 	HIPCHK(hipEventRecord(h->ev[2], st));
 	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
