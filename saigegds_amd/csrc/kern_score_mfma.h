@@ -21,8 +21,9 @@
 // Planes.  A = raw 2-bit codes (0,1,2,3) against all limb columns gives
 //     V[c] = T1 + 2 T2 + 3 T3      (T_g = sum of q over samples with code g)
 // A' = bit 1 of the code against the mu2 limbs gives  B1 = T2 + T3  (mu2 only),
-// and the rare missing entries (code 3) are summed exactly on a side path,
-// T3[c] and n3.  From these, in integer arithmetic,
+// and A'' = [code == 3] against the value columns gives T3[c] and n3; that plane
+// is only multiplied in fragments in which a wave sees a missing code.  From
+// these, in integer arithmetic,
 //     W[c] = V[c] - 3 T3[c] = T1 + 2 T2,   H2 = B1 - T3[mu2] = T2[mu2],
 //     AC = V[ones] - 3 n3,   Num = N - n3,
 // and with imp = 2 AF the sums the epilogue needs (dev_common.h):
@@ -38,13 +39,12 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define MF_VPB (MF_VPW * MF_WAVES)
 #define MF_NLIMB 7
 #define MF_MAXP 10           /* 2K+2 supported by the MFMA path (K <= 4)     */
-#define MF_QCAP 128          /* per-wave queue of missing entries            */
 
 struct MfTab {
 	const uint8_t *Fl;         // [ngrp_pad][ncol][16] int8 limb digits, sample-fastest
-	const unsigned long long *Fq;   // [N][P] fixed-point values (two's complement int64)
-	int ncol;                  // 16 * (nbfv + 1)
+	int ncol;                  // 16 * (nbfv + 1): columns of one B tile
 	int nbfv;                  // B fragments used with the value plane
+	int nacc;                  // ints per variant in the accumulator buffer = ncol + 16 * nbfv
 	int col_ones;              // column of the constant 1
 	int col_b1;                // first column of the mu2 limbs in the bit-1 fragment
 	int ntile;                 // number of 256-sample tiles = ngrp_pad / 16
@@ -53,7 +53,7 @@ struct MfTab {
 	long long ftot_lo[MF_MAXP];
 };
 
-// 16 two-bit codes -> 16 bytes (value plane) and twice their bit 1 (0/2 bytes)
+// 16 two-bit codes -> 16 bytes: value plane (0..3) and twice their bit 1 (0/2)
 __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 {
 #pragma unroll
@@ -66,42 +66,22 @@ __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 	}
 }
 
-// Flush the wave's queue of missing entries: one entry per lane, gather the
-// fixed-point row and add it to the wave's LDS table (exact integer adds).
-template <int P>
-__device__ __forceinline__ void mf_flush_missing(int cnt, const uint32_t *q, const MfTab &tb,
-	unsigned long long *t3lo, long long *t3hi, int *n3, int lane)
-{
-	for (int k = lane; k < cnt; k += WAVE) {
-		const uint32_t e = q[k];
-		const int vl = (int)(e >> 26), i = (int)(e & 0x03FFFFFFu);
-		const unsigned long long *fq = tb.Fq + (size_t)i * P;
-#pragma unroll
-		for (int c = 0; c < P; c++) {
-			const unsigned long long x = fq[c];
-			atomicAdd(&t3lo[vl * P + c], (unsigned long long)(uint32_t)x);
-			atomicAdd((unsigned long long *)&t3hi[vl * P + c], (unsigned long long)((long long)x >> 32));
-		}
-		atomicAdd(&n3[vl], 1);
-	}
-}
-
-// grid = (variant tiles of MF_VPB, sample splits); block = 64 * MF_WAVES
+// grid = (variant tiles of MF_VPB, sample splits); block = 64 * MF_WAVES.
+// Accumulator row of a variant: [0, ncol) value plane + bit-1 fragment,
+// [ncol, ncol + 16 nbfv) the same value columns summed over MISSING samples only
+// (plane [code == 3]); that plane is multiplied only in fragments that contain
+// a missing code, which a wave decides with one ballot.
 template <int NBFV, int P>
 __global__ void __launch_bounds__(WAVE * MF_WAVES, 2)
-score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, int N, MfTab tb,
-	int tiles_per_split, int *__restrict__ accbuf, unsigned long long *__restrict__ t3g_lo,
-	long long *__restrict__ t3g_hi, int *__restrict__ n3g)
+score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab tb,
+	int tiles_per_split, int *__restrict__ accbuf)
 {
 	constexpr int NBF = NBFV + 1;
 	constexpr int NCOL = 16 * NBF;
+	constexpr int NACC = NCOL + 16 * NBFV;
 	constexpr int TILE_BYTES = 16 * NCOL * 16;
-	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-	uint8_t *ldsB = smem;                                              // 2 x TILE_BYTES (double buffer)
-	unsigned long long *t3lo = reinterpret_cast<unsigned long long *>(smem + 2 * TILE_BYTES);   // [WAVES][64][P]
-	long long *t3hi = reinterpret_cast<long long *>(t3lo + MF_WAVES * MF_VPW * P);
-	int *n3 = reinterpret_cast<int *>(t3hi + MF_WAVES * MF_VPW * P);   // [WAVES][64]
-	uint32_t *mq = reinterpret_cast<uint32_t *>(n3 + MF_WAVES * MF_VPW);   // [WAVES][QCAP]
+	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // 2 x TILE_BYTES, nothing else
+	uint8_t *ldsB = smem;
 
 	const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
 	const int r = lane & 15, kg = lane >> 4;
@@ -109,28 +89,22 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, int N, 
 	const int t0 = blockIdx.y * tiles_per_split;
 	const int t1 = min(tb.ntile, t0 + tiles_per_split);
 
-	unsigned long long *my_lo = t3lo + wid * MF_VPW * P;
-	long long *my_hi = t3hi + wid * MF_VPW * P;
-	int *my_n3 = n3 + wid * MF_VPW;
-	uint32_t *my_q = mq + wid * MF_QCAP;
-	for (int k = lane; k < MF_VPW * P; k += WAVE) { my_lo[k] = 0; my_hi[k] = 0; }
-	my_n3[lane] = 0;
-	int qn = 0;   // wave-uniform queue fill
-
-	v4i acc[MF_NAF][NBF];
-#pragma unroll
-	for (int f = 0; f < MF_NAF; f++)
-#pragma unroll
-		for (int b = 0; b < NBF; b++) acc[f][b] = (v4i){0, 0, 0, 0};
-
-	const uint8_t *rowp[MF_NAF];
-	bool vok[MF_NAF];
+	v4i acc[MF_NAF][NBF], accm[MF_NAF][NBFV];
 #pragma unroll
 	for (int f = 0; f < MF_NAF; f++) {
-		const int v = vbase + 16 * f + r;
-		vok[f] = v < M;
-		rowp[f] = packed + (size_t)(vok[f] ? v : 0) * bpv;
+#pragma unroll
+		for (int b = 0; b < NBF; b++) acc[f][b] = (v4i){0, 0, 0, 0};
+#pragma unroll
+		for (int b = 0; b < NBFV; b++) accm[f][b] = (v4i){0, 0, 0, 0};
 	}
+	bool saw_missing = false;   // wave-uniform
+
+	// row pointers advance by 64 B per tile; bpv is a multiple of 64 that covers every
+	// tile (sgx_row_stride), rows past M are clamped (their sums are never stored)
+	const uint8_t *rowp[MF_NAF];
+#pragma unroll
+	for (int f = 0; f < MF_NAF; f++)
+		rowp[f] = packed + (size_t)min(vbase + 16 * f + r, M - 1) * bpv + (size_t)t0 * 64 + 16 * kg;
 
 	// B tile t -> LDS buffer (t & 1) by LDS-DMA: 1 KiB per wave-instruction, lane-linear
 	auto issue_B = [&](int t) {
@@ -142,21 +116,20 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, int N, 
 				(const __attribute__((address_space(1))) void *)(src + (size_t)k * 1024 + lane * 16),
 				(__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
 	};
-	// this lane's 64 samples of each of its 4 variants in tile t: dwords 16t+4kg .. +3
-	auto load_A = [&](int t, uint4 (&a)[MF_NAF]) {
-		const size_t boff = ((size_t)16 * t + 4 * kg) * 4;
+	// this lane's 64 samples of each of its variants in tile t: dwords 16t+4kg .. +3
+	auto load_A = [&](uint4 (&a)[MF_NAF]) {
 #pragma unroll
 		for (int f = 0; f < MF_NAF; f++) {
-			a[f] = make_uint4(0, 0, 0, 0);
-			if (vok[f] && boff + 16 <= bpv) a[f] = *reinterpret_cast<const uint4 *>(rowp[f] + boff);
+			a[f] = *reinterpret_cast<const uint4 *>(rowp[f]);
+			rowp[f] += 64;
 		}
 	};
 
 	uint4 acur[MF_NAF], anxt[MF_NAF];
-	if (t0 < t1) { load_A(t0, acur); issue_B(t0); }
+	if (t0 < t1) { load_A(acur); issue_B(t0); }
 	for (int t = t0; t < t1; t++) {
 		__syncthreads();   // tile t landed (each wave drained its own DMA), tile t-1 fully consumed
-		if (t + 1 < t1) { load_A(t + 1, anxt); issue_B(t + 1); }
+		if (t + 1 < t1) { load_A(anxt); issue_B(t + 1); }
 		const uint8_t *bt = ldsB + (size_t)(t & 1) * TILE_BYTES;
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
@@ -174,32 +147,21 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, int N, 
 				for (int b = 0; b < NBFV; b++)
 					acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(val, bfrag[b], acc[f][b], 0, 0, 0);
 				acc[f][NBFV] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, bfrag[NBFV], acc[f][NBFV], 0, 0, 0);
-				// missing entries (code 3) -> wave queue
-				uint32_t m = w & (w >> 1) & LO_MASK;
-				const int sbase = (16 * t + g) * 16;
-				if (sbase + 16 > N) m &= keep_mask(N - sbase);
-				unsigned long long any = __ballot(m != 0);
-				while (any) {
-					const bool has = m != 0;
-					if (has) {
-						const int b = __ffs(m) - 1;
-						m &= m - 1;
-						const int pos = qn + __popcll(any & ((1ull << lane) - 1ull));
-						my_q[pos] = ((uint32_t)(16 * f + r) << 26) | (uint32_t)(sbase + (b >> 1));
-					}
-					qn += __popcll(any);
-					any = __ballot(m != 0);
-					if (qn > MF_QCAP - WAVE) {
-						mf_flush_missing<P>(qn, my_q, tb, my_lo, my_hi, my_n3, lane);
-						qn = 0;
-					}
+				// samples beyond N have all-zero limbs, so stray codes there add nothing
+				if (__ballot((w & (w >> 1) & LO_MASK) != 0)) {
+					saw_missing = true;
+					v4i ms;
+#pragma unroll
+					for (int k = 0; k < 4; k++) ms[k] = (int)((uint32_t)val[k] & ((uint32_t)val[k] >> 1) & 0x01010101u);
+#pragma unroll
+					for (int b = 0; b < NBFV; b++)
+						accm[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ms, bfrag[b], accm[f][b], 0, 0, 0);
 				}
 			}
 		}
 #pragma unroll
 		for (int f = 0; f < MF_NAF; f++) acur[f] = anxt[f];
 	}
-	mf_flush_missing<P>(qn, my_q, tb, my_lo, my_hi, my_n3, lane);
 
 	// ---- results: integer atomics (exact, order-independent)
 #pragma unroll
@@ -208,21 +170,14 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, int N, 
 		for (int reg = 0; reg < 4; reg++) {
 			const int v = vbase + 16 * f + kg * 4 + reg;
 			if (v < M) {
+				int *dst = accbuf + (size_t)v * NACC;
 #pragma unroll
-				for (int b = 0; b < NBF; b++)
-					atomicAdd(&accbuf[(size_t)v * NCOL + b * 16 + r], acc[f][b][reg]);
-			}
-		}
-	}
-	{
-		const int v = vbase + lane;
-		const int c3 = my_n3[lane];
-		if (v < M && c3 > 0) {
-			atomicAdd(&n3g[v], c3);
+				for (int b = 0; b < NBF; b++) atomicAdd(&dst[b * 16 + r], acc[f][b][reg]);
+				if (saw_missing) {
 #pragma unroll
-			for (int c = 0; c < P; c++) {
-				atomicAdd(&t3g_lo[(size_t)v * P + c], my_lo[lane * P + c]);
-				atomicAdd((unsigned long long *)&t3g_hi[(size_t)v * P + c], (unsigned long long)my_hi[lane * P + c]);
+					for (int b = 0; b < NBFV; b++)
+						if (accm[f][b][reg] != 0) atomicAdd(&dst[NCOL + b * 16 + r], accm[f][b][reg]);
+				}
 			}
 		}
 	}
@@ -249,15 +204,15 @@ __device__ __forceinline__ HiLo mf_limbs(const int *a)
 template <int P>
 __global__ void __launch_bounds__(256)
 score_mfma_epilogue(int M, DevModel md, MfTab tb, const int *__restrict__ accbuf,
-	const unsigned long long *__restrict__ t3g_lo, const long long *__restrict__ t3g_hi,
-	const int *__restrict__ n3g, SpaRec *__restrict__ recs, int *__restrict__ counters,
-	double *__restrict__ out8, uint8_t *__restrict__ valid)
+	SpaRec *__restrict__ recs, int *__restrict__ counters, double *__restrict__ out8,
+	uint8_t *__restrict__ valid)
 {
 	const int j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= M) return;
-	const int *a = accbuf + (size_t)j * tb.ncol;
-	const int n3 = n3g[j];
+	const int *a = accbuf + (size_t)j * tb.nacc;     // value plane + bit-1 fragment
+	const int *am = a + tb.ncol;                      // value columns over missing samples
 	const int N = md.N;
+	const int n3 = am[tb.col_ones];
 	const long long AC = (long long)a[tb.col_ones] - 3ll * n3;
 	const int n2 = a[tb.col_b1 + MF_NLIMB] / 2 - n3;       // bit-1 plane (0/2) against the ones column
 	const int n1 = (int)(AC - 2ll * n2);
@@ -270,7 +225,7 @@ score_mfma_epilogue(int M, DevModel md, MfTab tb, const int *__restrict__ accbuf
 #pragma unroll
 	for (int c = 0; c < P; c++) {
 		const HiLo V = mf_limbs(a + c * MF_NLIMB);
-		const HiLo T3 = hl(t3g_hi[(size_t)j * P + c], (long long)t3g_lo[(size_t)j * P + c]);
+		const HiLo T3 = mf_limbs(am + c * MF_NLIMB);
 		const HiLo W = hl_axpy(-3, T3, V);
 		const double t3d = hl_to_double(T3);
 		double s;

@@ -87,9 +87,8 @@ struct sgx_handle {
 	// exact-integer MFMA score path (kern_score_mfma.h)
 	bool mf_ok = false;
 	MfTab mf{};
-	uint8_t *dFl = nullptr; unsigned long long *dFq = nullptr;
-	int *mf_acc = nullptr; unsigned long long *mf_t3lo = nullptr; long long *mf_t3hi = nullptr;
-	int *mf_n3 = nullptr; size_t mf_cap = 0;
+	uint8_t *dFl = nullptr;
+	int *mf_acc = nullptr;
 	int n_cu = 256;
 	int *counters = nullptr;          // [0] n_spa, [1] n_valid, [2] n_fallback
 	int *h_counters = nullptr;        // pinned
@@ -121,7 +120,7 @@ extern "C" int sgx_device_count(void)
 
 extern "C" size_t sgx_row_stride(int32_t n_samp)
 {
-	return (size_t)((n_samp + 63) / 64) * 16;
+	return (size_t)((n_samp + 255) / 256) * 64;   // whole 256-sample tiles (kern_score_mfma.h)
 }
 
 static double thr_or(double v, double dflt) { return std::isfinite(v) ? v : dflt; }
@@ -191,19 +190,18 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 	}
 	// fixed-point limb tables for the MFMA score path (binary and quantitative alike)
 	std::vector<int8_t> Fl;
-	std::vector<unsigned long long> Fq;
 	if (P <= MF_MAXP && (double)N * 384.0 < 2147483647.0) {
 		MfTab &tb = h->mf;
 		const int ncolv = MF_NLIMB * P + 1;
 		tb.nbfv = (ncolv + 15) / 16;
 		tb.ncol = 16 * (tb.nbfv + 1);
+		tb.nacc = tb.ncol + 16 * tb.nbfv;
 		tb.col_ones = MF_NLIMB * P;
 		tb.col_b1 = 16 * tb.nbfv;
 		const int ngrp = (N + 15) / 16;
 		tb.ntile = (ngrp + 15) / 16;
 		const size_t ngrp_pad = (size_t)tb.ntile * 16;
 		Fl.assign(ngrp_pad * tb.ncol * 16, 0);
-		Fq.assign((size_t)N * P, 0);
 		for (int c = 0; c < P; c++) {
 			double mx = 0;
 			for (int i = 0; i < N; i++) mx = std::max(mx, std::fabs(F[(size_t)i * P + c]));
@@ -213,7 +211,6 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 			__int128 tot = 0;
 			for (int i = 0; i < N; i++) {
 				long long q = std::llrint(std::ldexp(F[(size_t)i * P + c], tb.escale[c]));
-				Fq[(size_t)i * P + c] = (unsigned long long)q;
 				tot += q;
 				int8_t *base = &Fl[((size_t)(i / 16) * tb.ncol) * 16 + (i % 16)];
 				long long rem = q;
@@ -251,8 +248,7 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 	if (h->mf_ok) {
 		std::vector<uint8_t> Flu(Fl.begin(), Fl.end());
 		TRY(dev_upload(&h->dFl, Flu));
-		TRY(dev_upload(&h->dFq, Fq));
-		h->mf.Fl = h->dFl; h->mf.Fq = h->dFq;
+		h->mf.Fl = h->dFl;
 	}
 	md.F = h->dF; md.X = h->dX; md.y = h->dy; md.mu = h->dmu; md.mu2 = h->dmu2; md.XM = h->dXM;
 	hipError_t e;
@@ -289,8 +285,7 @@ extern "C" void sgx_free(sgx_handle *h)
 	(void)hipFree(h->dF); (void)hipFree(h->dX); (void)hipFree(h->dy);
 	(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->fallback); (void)hipFree(h->fb_spa2); (void)hipFree(h->heads);
 	(void)hipFree(h->arena); (void)hipFree(h->cursor); (void)hipFree(h->segcnt); (void)hipFree(h->segpart); (void)hipFree(h->chunks); (void)hipFree(h->partial);
-	(void)hipFree(h->dFl); (void)hipFree(h->dFq); (void)hipFree(h->mf_acc);
-	(void)hipFree(h->mf_t3lo); (void)hipFree(h->mf_t3hi); (void)hipFree(h->mf_n3);
+	(void)hipFree(h->dFl); (void)hipFree(h->mf_acc);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
 	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
@@ -328,14 +323,8 @@ static int ensure_recs(sgx_handle *h, size_t n)
 	}
 	if (h->mf_ok) {
 		if (h->mf_acc) HIPCHK(hipFree(h->mf_acc));
-		if (h->mf_t3lo) HIPCHK(hipFree(h->mf_t3lo));
-		if (h->mf_t3hi) HIPCHK(hipFree(h->mf_t3hi));
-		if (h->mf_n3) HIPCHK(hipFree(h->mf_n3));
-		h->mf_acc = nullptr; h->mf_t3lo = nullptr; h->mf_t3hi = nullptr; h->mf_n3 = nullptr;
-		HIPCHK(hipMalloc((void **)&h->mf_acc, n * (size_t)h->mf.ncol * sizeof(int)));
-		HIPCHK(hipMalloc((void **)&h->mf_t3lo, n * (size_t)h->md.P * sizeof(long long)));
-		HIPCHK(hipMalloc((void **)&h->mf_t3hi, n * (size_t)h->md.P * sizeof(long long)));
-		HIPCHK(hipMalloc((void **)&h->mf_n3, n * sizeof(int)));
+		h->mf_acc = nullptr;
+		HIPCHK(hipMalloc((void **)&h->mf_acc, n * (size_t)h->mf.nacc * sizeof(int)));
 	}
 	h->recs_cap = n;
 	return SGX_OK;
@@ -359,10 +348,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	if (use_mf) {
 		const MfTab &tb = h->mf;
 		const int P = md.P;
-		HIPCHK(hipMemsetAsync(h->mf_acc, 0, M * (size_t)tb.ncol * sizeof(int), st));
-		HIPCHK(hipMemsetAsync(h->mf_t3lo, 0, M * (size_t)P * sizeof(long long), st));
-		HIPCHK(hipMemsetAsync(h->mf_t3hi, 0, M * (size_t)P * sizeof(long long), st));
-		HIPCHK(hipMemsetAsync(h->mf_n3, 0, M * sizeof(int), st));
+		HIPCHK(hipMemsetAsync(h->mf_acc, 0, M * (size_t)tb.nacc * sizeof(int), st));
 		const int vt = (int)((M + MF_VPB - 1) / MF_VPB);
 		// split the samples so that the grid is a few rounds of 2 workgroups per CU
 		int sk = std::max(1, (h->n_cu * 2 * 4 + vt / 2) / vt);
@@ -370,15 +356,12 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		const int tps = (tb.ntile + sk - 1) / sk;
 		sk = (tb.ntile + tps - 1) / tps;
 		const dim3 mgrid((unsigned)vt, (unsigned)sk);
-		const size_t lds = (size_t)2 * 16 * tb.ncol * 16 + (size_t)MF_WAVES * MF_VPW * P * 16 +
-			(size_t)MF_WAVES * MF_VPW * 4 + (size_t)MF_WAVES * MF_QCAP * 4;
+		const size_t lds = (size_t)2 * 16 * tb.ncol * 16;
 #define MFCASE(NB, PP)                                                                        \
 	hipLaunchKernelGGL((score_mfma_kernel<NB, PP>), mgrid, dim3(WAVE * MF_WAVES), lds, st,      \
-		(const uint8_t *)rows, row_bytes, (int)M, md.N, tb, tps, h->mf_acc, h->mf_t3lo,        \
-		h->mf_t3hi, h->mf_n3);                                                                 \
+		(const uint8_t *)rows, row_bytes, (int)M, tb, tps, h->mf_acc);                         \
 	hipLaunchKernelGGL((score_mfma_epilogue<PP>), dim3((unsigned)((M + 255) / 256)), dim3(256), \
-		0, st, (int)M, md, tb, h->mf_acc, h->mf_t3lo, h->mf_t3hi, h->mf_n3, h->recs,           \
-		h->counters, out8, valid);
+		0, st, (int)M, md, tb, h->mf_acc, h->recs, h->counters, out8, valid);
 		switch (P) {
 		case 4: MFCASE(2, 4) break;
 		case 6: MFCASE(3, 6) break;
@@ -503,8 +486,8 @@ extern "C" int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev, size_
 	if (!packed_dev || !out8_dev || !valid_dev)
 		return fail(SGX_EINVAL, "sgx_scan_2bit_dev: NULL buffer");
 	if (M > 0x7fffffffu) return fail(SGX_EINVAL, "sgx_scan_2bit_dev: too many variants in one call");
-	if (bpv % 16 != 0 || bpv < sgx_row_stride(h->md.N))
-		return fail(SGX_EINVAL, "Invalid length of dosages: bytes_per_variant=%zu, need a multiple of 16 >= %zu",
+	if (bpv % 64 != 0 || bpv < sgx_row_stride(h->md.N))
+		return fail(SGX_EINVAL, "Invalid length of dosages: bytes_per_variant=%zu, need a multiple of 64 >= %zu",
 			bpv, sgx_row_stride(h->md.N));
 	if (((uintptr_t)packed_dev & 15u) != 0)
 		return fail(SGX_EINVAL, "sgx_scan_2bit_dev: packed_dev must be 16-byte aligned");
