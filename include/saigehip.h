@@ -104,7 +104,8 @@ typedef struct sgx_stats {
 const char *sgx_version(void);
 const char *sgx_last_error(void);
 int sgx_device_count(void);
-/* verifies the v_mfma_i32_16x16x64_i8 lane maps the score kernel relies on */
+/* verifies the v_mfma_i32_16x16x64_i8 lane maps the score kernel relies on and
+ * the accuracy of the device exp/log used by the SPA stage */
 int sgx_selftest(int device);
 
 /* Model lifetime (one handle per GPU; handles are independent, no globals). */

@@ -244,9 +244,14 @@ spa3_head(DevModel md, int nseg, const SpaRec *__restrict__ recs, int *__restric
 				fb_spa2[atomicAdd(&counters[3], 1)] = v;
 			} else {
 				atomicMax(&counters[6], c0 + nch);     // chunks the pass kernels may touch
-				h.c0 = c0; h.nchunks = nch; h.state = 1;
+				h.c0 = c0; h.nchunks = nch;
 				root_begin(h.s1, h.qtilde, L, U);
 				root_begin(h.s2, h.qinv, L, U);
+				// the evaluation at t = 0 needs no pass: exp(0) = 1 turns the K1 and K2
+				// sums (SPATest.cpp:64,79) into sum g mu and sum g^2 mu (1-mu)
+				root_feed(h.s1, a6[4], a6[5], h.NAmu, h.NAsigma);
+				root_feed(h.s2, a6[4], a6[5], h.NAmu, h.NAsigma);
+				h.state = (h.s1.active || h.s2.active) ? 1 : ((h.s1.converged && h.s2.converged) ? 2 : 3);
 				for (int k = 0; k < nch; k++) { chunks[c0 + k].v = v; chunks[c0 + k].k = k; }
 			}
 		}
@@ -270,25 +275,33 @@ spa3_pass(const int *__restrict__ counters, const ChunkDesc *__restrict__ chunks
 		const int beg = cd.k * SPA3_CHUNK, end = min(h->nnz, beg + SPA3_CHUNK);
 		const double2 *lst = arena + h->off;
 		double v[4] = {0, 0, 0, 0};
-		for (int k = beg + threadIdx.x; k < end; k += SPA3_BLOCK) {
-			const double2 gm = lst[k];
-			const double g = gm.x, m = gm.y, om = 1 - m;
-			const double mg = m * g, c2 = om * mg * g;
-			if (a1) {
-				const double e = exp(-g * t1);
-				const double d = fma(om, e, m);
-				const double rr = isfinite(d) ? fast_rcp(d) : 0.0;
-				v[0] = fma(mg, rr, v[0]);
-				const double tt = c2 * e * rr * rr;
-				if (isfinite(tt)) v[1] += tt;
+		for (int k0 = beg + threadIdx.x; k0 < end; k0 += 4 * SPA3_BLOCK) {
+			double2 gm4[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {          // four independent loads in flight
+				const int k = k0 + j * SPA3_BLOCK;
+				gm4[j] = (k < end) ? lst[k] : make_double2(0.0, 0.5);   // g = 0 adds exactly 0
 			}
-			if (a2) {
-				const double e = exp(-g * t2);
-				const double d = fma(om, e, m);
-				const double rr = isfinite(d) ? fast_rcp(d) : 0.0;
-				v[2] = fma(mg, rr, v[2]);
-				const double tt = c2 * e * rr * rr;
-				if (isfinite(tt)) v[3] += tt;
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const double g = gm4[j].x, m = gm4[j].y, om = 1 - m;
+				const double mg = m * g, c2 = om * mg * g;
+				if (a1) {
+					const double e = fast_exp(-g * t1);
+					const double d = fma(om, e, m);
+					const double rr = isfinite(d) ? fast_rcp(d) : 0.0;
+					v[0] = fma(mg, rr, v[0]);
+					const double tt = c2 * e * rr * rr;
+					if (isfinite(tt)) v[1] += tt;
+				}
+				if (a2) {
+					const double e = fast_exp(-g * t2);
+					const double d = fma(om, e, m);
+					const double rr = isfinite(d) ? fast_rcp(d) : 0.0;
+					v[2] = fma(mg, rr, v[2]);
+					const double tt = c2 * e * rr * rr;
+					if (isfinite(tt)) v[3] += tt;
+				}
 			}
 		}
 		block_sum<4, SPA3_BLOCK>(v, sh);
@@ -331,11 +344,19 @@ spa3_korg(const int *__restrict__ counters, const ChunkDesc *__restrict__ chunks
 		const int beg = cd.k * SPA3_CHUNK, end = min(h->nnz, beg + SPA3_CHUNK);
 		const double2 *lst = arena + h->off;
 		double v[2] = {0, 0};
-		for (int k = beg + threadIdx.x; k < end; k += SPA3_BLOCK) {
-			const double2 gm = lst[k];
-			const double g = gm.x, m = gm.y, om = 1 - m;
-			v[0] += log(fma(m, exp(g * t1), om));
-			v[1] += log(fma(m, exp(g * t2), om));
+		for (int k0 = beg + threadIdx.x; k0 < end; k0 += 4 * SPA3_BLOCK) {
+			double2 gm4[4];
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const int k = k0 + j * SPA3_BLOCK;
+				gm4[j] = (k < end) ? lst[k] : make_double2(0.0, 0.5);   // log(1) = 0
+			}
+#pragma unroll
+			for (int j = 0; j < 4; j++) {
+				const double g = gm4[j].x, m = gm4[j].y, om = 1 - m;
+				v[0] += fast_log(fma(m, fast_exp(g * t1), om));
+				v[1] += fast_log(fma(m, fast_exp(g * t2), om));
+			}
 		}
 		block_sum<2, SPA3_BLOCK>(v, sh);
 		if (threadIdx.x == 0) partial[ci] = make_double4(v[0], v[1], 0, 0);

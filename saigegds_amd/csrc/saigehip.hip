@@ -626,5 +626,36 @@ extern "C" int sgx_selftest(int device)
 	(void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dD);
 	for (int i = 0; i < 256; i++)
 		if (D[i] != R[i]) return fail(SGX_EHIP, "sgx_selftest: MFMA i8 lane map mismatch at %d: %d != %d", i, D[i], R[i]);
+
+	// fast_exp / fast_log (kern_spa2.h) against the host libm
+	const int NT = 8192;
+	std::vector<double> xin(2 * NT), yout(2 * NT);
+	for (int i = 0; i < NT; i++) {
+		x = splitmix64(x);
+		const double u = (double)(x >> 11) / 9007199254740992.0;
+		xin[i] = (i < 16) ? (double[]){0.0, -0.0, 1.0, -1.0, 709.7, 709.79, -745.0, -745.2, -708.4, 1e-300, -1e-300, 0.34657, -0.34657, 50.0, -50.0, 710.0}[i]
+			: (i & 1 ? -745.0 + u * 1455.0 : -2.0 + 4.0 * u);
+		x = splitmix64(x);
+		const double w = (double)(x >> 11) / 9007199254740992.0;
+		xin[NT + i] = (i < 8) ? (double[]){1.0, 0.5, 2.0, 0.70710678118654746, 0.70710678118654757, 1.0000000000000002, 0.99999999999999989, 1e308}[i]
+			: (i & 1 ? std::pow(10.0, -300.0 + 600.0 * w) : 1.0 + (w - 0.5) * std::pow(10.0, -(double)(i % 16)));
+	}
+	double *dx, *dy;
+	HIPCHK(hipMalloc((void **)&dx, xin.size() * sizeof(double)));
+	HIPCHK(hipMalloc((void **)&dy, xin.size() * sizeof(double)));
+	HIPCHK(hipMemcpy(dx, xin.data(), xin.size() * sizeof(double), hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(fastmath_selftest_kernel, dim3((2 * NT + 255) / 256), dim3(256), 0, 0, dx, dy, NT);
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(yout.data(), dy, yout.size() * sizeof(double), hipMemcpyDeviceToHost));
+	(void)hipFree(dx); (void)hipFree(dy);
+	for (int i = 0; i < 2 * NT; i++) {
+		const double ref = (i < NT) ? std::exp(xin[i]) : std::log(xin[i]);
+		const double got = yout[i];
+		const bool same = (ref == got) || (std::isnan(ref) && std::isnan(got));
+		// log near 1 is tiny: allow an absolute 4e-17 there, else 1.5e-15 relative
+		const double tol = 1.5e-15 * std::fabs(ref) + ((i >= NT) ? 4e-17 : 0.0) + ((i < NT && ref < 1e-300) ? 1e-320 : 0.0);
+		if (!same && !(std::fabs(got - ref) <= tol))
+			return fail(SGX_EHIP, "sgx_selftest: fast %s(%.17g) = %.17g, libm %.17g", i < NT ? "exp" : "log", xin[i], got, ref);
+	}
 	return SGX_OK;
 }
