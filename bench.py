@@ -4,7 +4,7 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path (score kernel + SPA kernel, through
+A "step" is one pass of the hot path (score stage + SPA stage, through
 sgx_scan_2bit_dev) over one block of 50 000 variants (the reference's
 seqParallel block size, R/assoc_single.r:204) of synthetic 2-bit genotypes that
 are already resident in this GPU's HBM.  Every step scans a different block.
@@ -131,23 +131,34 @@ def main():
         elapsed = float(tmax.item())
 
     # ---- per-kernel figures (rank 0's launches) ----------------------------
+    # HIP events recorded by the library on ITS stream around the score stage
+    # (score_mfma_kernel + its 40 us epilogue) and around the SPA stage (spa3_* kernels).
     ms_score = float(np.mean([s["ms_score"] for s in st_all]))
     ms_spa = float(np.mean([s["ms_spa"] for s in st_all]))
     n_spa = int(np.sum([s["n_spa"] for s in st_all]))
     n_valid = int(np.sum([s["n_valid"] for s in st_all]))
     nv_tot = steps * block
     alg_bytes = block * (math.ceil(n / 4) + 64)      # ceil(N/4)+64 B per variant
-    dom = "score2b_kernel" if ms_score >= ms_spa else "spa_kernel"
-    dom_ms = max(ms_score, ms_spa)
-    achieved = alg_bytes / (dom_ms * 1e-3) / 1e9
+    # dominant kernel = the one launch that streams the packed genotypes (the SPA
+    # stage is ~30 short launches, none longer than it; profiles/r01_*_kernel_stats.csv)
+    score_kernel = "score_mfma_kernel" if args.k <= 4 else "score2b_kernel"
+    achieved = alg_bytes / (ms_score * 1e-3) / 1e9
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_score.json")
+    if os.path.exists(pmc_file):
+        pm = json.load(open(pmc_file))
+        if pm.get("n_samples") == n and pm.get("variants_per_launch") == block and pm.get("kernel") == score_kernel:
+            traffic = pm["hbm_bytes_per_launch"]
     roofline = {
-        "bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(dom_ms, 4),
-        "kernels": {
-            "score2b_kernel": {"avg_ms": round(ms_score, 4),
-                               "hbm_gbs": round(alg_bytes / (ms_score * 1e-3) / 1e9, 2) if ms_score > 0 else None},
-            "spa_kernel": {"avg_ms": round(ms_spa, 4), "variants_per_launch": n_spa / max(1, steps)},
+        "bound": "hbm", "kernel": score_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms_score, 4),
+        "stages": {
+            "score": {"avg_ms": round(ms_score, 4), "launches_per_step": int(st_all[0]["score_launches"])},
+            "spa": {"avg_ms": round(ms_spa, 4), "launches_per_step": int(st_all[0]["spa_launches"]),
+                    "variants_per_step": n_spa / max(1, steps),
+                    "dense_fallback": int(np.sum([s["n_spa_dense"] for s in st_all])),
+                    "slow_path": int(np.sum([s["n_spa_slow"] for s in st_all]))},
         },
         "whole_step_gbs": round(alg_bytes * steps / elapsed / 1e9, 2),
     }

@@ -135,6 +135,12 @@ int sgx_scan_u8(sgx_handle *h, const uint8_t *dosage, size_t n_variants,
 int sgx_scan_f64(sgx_handle *h, const double *dosage, size_t n_variants,
 	double *out8, uint8_t *valid);
 
+/* Tuning / test hooks: "spa_levels" (Newton levels run in lock step before
+ * stragglers go to the per-workgroup kernel), "arena_limit" (carriers; 0 = all),
+ * "score_v1" (gather kernel instead of the MFMA path), "force_dense" (exact
+ * g_pos/g_neg pass for every SPA variant).  Results never depend on them. */
+int sgx_set_option(sgx_handle *h, const char *name, long long value);
+
 int sgx_sync(sgx_handle *h);
 int sgx_get_stats(sgx_handle *h, sgx_stats *st);
 

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libsaigehip.so")
 EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
     "sgx_set_thresholds", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64",
-    "sgx_sync", "sgx_get_stats", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest",
+    "sgx_sync", "sgx_get_stats", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
 )
 
 
@@ -102,6 +102,8 @@ def load():
     L.sgx_scan_u8.argtypes = [vp, vp, sz, vp, vp]
     L.sgx_scan_f64.restype = C.c_int
     L.sgx_scan_f64.argtypes = [vp, vp, sz, vp, vp]
+    L.sgx_set_option.restype = C.c_int
+    L.sgx_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
     L.sgx_sync.restype = C.c_int
     L.sgx_sync.argtypes = [vp]
     L.sgx_get_stats.restype = C.c_int
@@ -212,6 +214,9 @@ class Scanner:
         st = SgxStats()
         check(self._L.sgx_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def set_option(self, name: str, value: int):
+        check(self._L.sgx_set_option(self._h, name.encode(), int(value)))
 
     def set_thresholds(self, maf, mac, missing, spa_pval):
         check(self._L.sgx_set_thresholds(self._h, maf, mac, missing, spa_pval))

@@ -201,7 +201,8 @@ template <int K>
 __global__ void __launch_bounds__(256)
 spa3_head(DevModel md, int nseg, const SpaRec *__restrict__ recs, int *__restrict__ counters,
 	const double *__restrict__ segpart, SpaHead *__restrict__ heads, ChunkDesc *__restrict__ chunks,
-	int chunk_cap, int *__restrict__ fb_dense, int *__restrict__ fb_spa2, double *__restrict__ out8)
+	int chunk_cap, int *__restrict__ fb_dense, int *__restrict__ fb_spa2, double *__restrict__ out8,
+	int force_dense)
 {
 	const int v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= counters[0]) return;
@@ -234,7 +235,7 @@ spa3_head(DevModel md, int nseg, const SpaRec *__restrict__ recs, int *__restric
 		const double nb = (xsum_c - a6[1]) * inv;
 		const double L = a6[2] + fmax(-nb, 0.0), U = a6[3] + fmin(-nb, 0.0);
 		const double mar = 1e-9 * (fabs(L) + fabs(U) + fabs(h.qtilde) + fabs(h.qinv));
-		if (!(h.qtilde < L - mar && h.qtilde > U + mar && h.qinv < L - mar && h.qinv > U + mar)) {
+		if (force_dense || !(h.qtilde < L - mar && h.qtilde > U + mar && h.qinv < L - mar && h.qinv > U + mar)) {
 			fb_dense[atomicAdd(&counters[2], 1)] = v;
 		} else {
 			const int nch = (nnz + SPA3_CHUNK - 1) / SPA3_CHUNK;

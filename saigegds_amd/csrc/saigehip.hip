@@ -84,6 +84,8 @@ struct sgx_handle {
 	ChunkDesc *chunks = nullptr; double4 *partial = nullptr; int chunk_cap = 0;
 	int *segcnt = nullptr; double *segpart = nullptr; int nseg = 0;
 	int spa_levels = 12;
+	unsigned long long arena_limit = 0;   // test hook: pretend the arena is this small (0 = real size)
+	bool force_dense = false;         // test hook: every SPA variant takes the exact dense pass
 	// exact-integer MFMA score path (kern_score_mfma.h)
 	bool mf_ok = false;
 	MfTab mf{};
@@ -406,13 +408,15 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			hipLaunchKernelGGL(spa3_count, gitem, dim3(256), 0, st, (const uint8_t *)rows,   \
 				row_bytes, md.N, h->nseg, h->recs, h->counters, h->segcnt);                  \
 			hipLaunchKernelGGL(spa3_plan, g256, dim3(256), 0, st, h->nseg, h->recs,          \
-				h->counters, h->cursor, h->arena_cap, h->segcnt, h->heads, h->fb_spa2);      \
+				h->counters, h->cursor,                                                      \
+				(h->arena_limit ? std::min(h->arena_limit, h->arena_cap) : h->arena_cap),    \
+				h->segcnt, h->heads, h->fb_spa2);      \
 			hipLaunchKernelGGL((spa3_fill<KK>), gitem, dim3(256), 0, st,                     \
 				(const uint8_t *)rows, row_bytes, md, h->nseg, h->recs, h->counters,         \
 				h->segcnt, h->heads, h->arena, h->segpart);                                  \
 			hipLaunchKernelGGL((spa3_head<KK>), g256, dim3(256), 0, st, md, h->nseg,         \
 				h->recs, h->counters, h->segpart, h->heads, h->chunks, h->chunk_cap,         \
-				h->fallback, h->fb_spa2, out8);                                              \
+				h->fallback, h->fb_spa2, out8, h->force_dense ? 1 : 0);                                              \
 			for (int lv = 0; lv < h->spa_levels; lv++) {                                     \
 				hipLaunchKernelGGL(spa3_pass, gchunk, dim3(SPA3_BLOCK), 0, st, h->counters,  \
 					h->chunks, h->heads, h->arena, h->partial);                              \
@@ -445,6 +449,19 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
 	h->stats.n_variants = M;
 	h->stats_pending = true;
+	return SGX_OK;
+}
+
+// Tuning / test hooks.  Unknown names are an error.
+extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
+{
+	if (!h || !name) return fail(SGX_EINVAL, "sgx_set_option: NULL argument");
+	const std::string n(name);
+	if (n == "spa_levels") { if (value < 0 || value > 1000) return fail(SGX_EINVAL, "spa_levels out of range"); h->spa_levels = (int)value; }
+	else if (n == "arena_limit") { if (value < 0) return fail(SGX_EINVAL, "arena_limit < 0"); h->arena_limit = (unsigned long long)value; }
+	else if (n == "score_v1") h->force_v1 = value != 0;
+	else if (n == "force_dense") h->force_dense = value != 0;
+	else return fail(SGX_EINVAL, "sgx_set_option: unknown option '%s'", name);
 	return SGX_OK;
 }
 

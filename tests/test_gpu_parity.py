@@ -188,6 +188,29 @@ def test_seqAssocGLMM_SPA_driver(grm1k, golden_bin, tmp_path):
     assert np.max(np.abs(np.asarray(r["pval"]) / golden_bin["pval"][keep] - 1)) <= 1e-10
 
 
+@pytest.mark.parametrize("option,value,counter", [
+    ("spa_levels", 1, "n_spa_slow"),      # stragglers finish in the per-workgroup kernel
+    ("arena_limit", 1000, "n_spa_slow"),  # carrier arena overflow
+    ("force_dense", 1, "n_spa_dense"),    # exact g_pos / g_neg pass (SPATest.cpp:328-332)
+    ("score_v1", 1, None),                # gather score kernel instead of the MFMA path
+])
+def test_fallback_paths_give_identical_rows(option, value, counter):
+    """Every slow path is the same algorithm: forcing it must not move a result."""
+    sm, packed = _synthetic_case(3001, 1200, "binary", 0.05, seed=23)
+    ref, ref_valid = _oracle(sm).scan_2bit(packed)
+    with _scanner(sm) as sc:
+        base, _ = sc.scan_2bit(packed)
+        assert sc.stats()["n_spa_slow"] == 0
+        sc.set_option(option, value)
+        out, valid = sc.scan_2bit(packed)
+        st = sc.stats()
+    if counter:
+        assert st[counter] > 10, st
+    assert_table_close(out, valid, ref, ref_valid, what=f"{option}={value}")
+    v = ref_valid.astype(bool)
+    np.testing.assert_allclose(out[v][:, 3:7], base[v][:, 3:7], rtol=1e-11)
+
+
 def test_mfma_lane_map_selftest():
     """v_mfma_i32_16x16x64_i8 operand/result lane maps assumed by the score kernel."""
     from saigegds_amd import _lib
