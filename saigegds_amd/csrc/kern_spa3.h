@@ -72,8 +72,10 @@ spa3_count(const uint8_t *__restrict__ packed, size_t bpv, int N, int nseg,
 	const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
 	const int nitem = counters[0] * nseg;
 	const int ndw = (N + 15) >> 4;
-	for (int it = blockIdx.x; it < nitem; it += gridDim.x) {
-		const int v = it / nseg, seg = it - v * nseg;
+	const int nflag = counters[0];
+	for (int wi = blockIdx.x; wi < nitem; wi += gridDim.x) {
+		const int seg = wi / nflag, v = wi - seg * nflag;   // segment-major order
+		const int it = v * nseg + seg;
 		const int minus = recs[v].minus;
 		const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (size_t)recs[v].j * bpv);
 		const uint32_t zx = minus ? 0xAAAAAAAAu : 0u;
@@ -125,8 +127,11 @@ spa3_fill(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg,
 	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
 	const int nitem = counters[0] * nseg;
 	const int ndw = (N + 15) >> 4;
-	for (int it = blockIdx.x; it < nitem; it += gridDim.x) {
-		const int v = it / nseg, seg = it - v * nseg;
+	const int nflag = counters[0];
+	for (int wi = blockIdx.x; wi < nitem; wi += gridDim.x) {
+		// segment-major: workgroups running together gather the same 8192 rows of XM (L2)
+		const int seg = wi / nflag, v = wi - seg * nflag;
+		const int it = v * nseg + seg;
 		if (heads[v].nnz < 0) continue;
 		const SpaRec r = recs[v];
 		const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (size_t)r.j * bpv);
