@@ -26,12 +26,13 @@ struct SpaRec {
 	int j;            // variant index in the block
 	int minus;        // AF > 0.5
 	int nnz;          // carriers: samples whose (imputed, flipped) dosage is non-zero
-	int pad_;
+	int has_gmu;      // sum_gmu is valid (MFMA score path)
 	double lut[4];    // dosage value per 2-bit code after impute + flip
 	double AC2;       // allele count of the tested (minor) allele
 	double p_noadj;
 	double S;         // score sum (y-mu).adj, unscaled
 	double var2;      // sum mu2 adj^2, unscaled (no variance ratio)
+	double sum_gmu;   // sum_i G_i mu_i over the (imputed, flipped) dosages
 	double c[KMAX];   // c' = XVX_inv_XV * G
 };
 

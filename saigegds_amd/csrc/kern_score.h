@@ -93,7 +93,7 @@ score2b_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, DevModel m
 			const int slot = atomicAdd(&counters[0], 1);
 			SpaRec r;
 			r.j = j; r.minus = h.minus; r.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
-			r.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); r.pad_ = 0;
+			r.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); r.has_gmu = 0; r.sum_gmu = 0;
 			r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc;
 			for (int a = 0; a < 4; a++) r.lut[a] = h.lut[a];
 			for (int a = 0; a < KMAX; a++) r.c[a] = (a < md.K) ? cbuf[a] : 0.0;
@@ -166,7 +166,7 @@ score_ds_kernel(const T *__restrict__ ds, int M, DevModel md, SpaRec *__restrict
 			const int slot = atomicAdd(&counters[0], 1);
 			SpaRec r;
 			r.j = j; r.minus = h.minus; r.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
-			r.nnz = 0; r.pad_ = 0;
+			r.nnz = 0; r.has_gmu = 0; r.sum_gmu = 0;
 			r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc;
 			// dosage rows carry real values: lut[3] holds the imputed value, the
 			// SPA kernel re-reads the row itself

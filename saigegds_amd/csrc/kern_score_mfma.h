@@ -48,9 +48,9 @@ struct MfTab {
 	int col_ones;              // column of the constant 1
 	int col_b1;                // first column of the mu2 limbs in the bit-1 fragment
 	int ntile;                 // number of 256-sample tiles = ngrp_pad / 16
-	int escale[MF_MAXP];       // F = q * 2^-escale
-	long long ftot_hi[MF_MAXP];     // sum_i q[i,c] = hi * 2^32 + lo
-	long long ftot_lo[MF_MAXP];
+	int escale[MF_MAXP + 1];   // F = q * 2^-escale; column P is mu (for the SPA stage's m1)
+	long long ftot_hi[MF_MAXP + 1]; // sum_i q[i,c] = hi * 2^32 + lo
+	long long ftot_lo[MF_MAXP + 1];
 };
 
 // 16 two-bit codes -> 16 bytes: value plane (0..3) and twice their bit 1 (0/2)
@@ -220,10 +220,10 @@ score_mfma_epilogue(int M, DevModel md, MfTab tb, const int *__restrict__ accbuf
 	double *o = out8 + (size_t)j * 8;
 	if (!h.pass) { nan_row(o); valid[j] = 0; return; }
 	const double imp = 2 * h.AF;
-	double acc[P];
+	double acc[P + 1];
 	HiLo Wm = hl(0, 0), T3m = hl(0, 0);
 #pragma unroll
-	for (int c = 0; c < P; c++) {
+	for (int c = 0; c < P + 1; c++) {
 		const HiLo V = mf_limbs(a + c * MF_NLIMB);
 		const HiLo T3 = mf_limbs(am + c * MF_NLIMB);
 		const HiLo W = hl_axpy(-3, T3, V);
@@ -255,7 +255,7 @@ score_mfma_epilogue(int M, DevModel md, MfTab tb, const int *__restrict__ accbuf
 		const int slot = atomicAdd(&counters[0], 1);
 		SpaRec rr;
 		rr.j = j; rr.minus = h.minus; rr.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
-		rr.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); rr.pad_ = 0;
+		rr.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); rr.has_gmu = 1; rr.sum_gmu = acc[P];
 		rr.p_noadj = pn; rr.S = Ssc; rr.var2 = v2sc;
 		for (int k = 0; k < 4; k++) rr.lut[k] = h.lut[k];
 		for (int k = 0; k < KMAX; k++) rr.c[k] = (k < md.K) ? cbuf[k] : 0.0;

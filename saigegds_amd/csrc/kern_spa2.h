@@ -25,12 +25,15 @@ struct RootState {
 	double t, root;    // current iterate / value returned by getroot_K1_fast
 	double K1_eval;    // K1_adj(t) + NAmu + NAsigma t
 	double K2cur;      // K2 sum at t
+	double Kcur;       // Korg sum at t (valid when k_ok)
 	double prevJump;
 	double tnew;       // point being evaluated
 	int it;
 	int phase;         // 0 first evaluation at t=0, 1 Newton candidate, 2 bisected candidate
 	bool active;       // needs another evaluation at tnew
 	bool converged;
+	bool want_k;       // the evaluation at tnew should include Korg (it is probably the last one)
+	bool k_ok;         // Kcur belongs to the current t
 };
 
 #define SPA_TOL 0.0001220703125   /* DBL_EPSILON^(1/4), SPATest.cpp:87 */
@@ -39,8 +42,9 @@ struct RootState {
 // start of getroot_K1_fast, SPATest.cpp:145-154
 __device__ __forceinline__ void root_begin(RootState &s, double q, double g_pos_lb, double g_neg_ub)
 {
-	s.q = q; s.t = 0; s.root = 0; s.K1_eval = 0; s.K2cur = 0; s.prevJump = INFINITY;
+	s.q = q; s.t = 0; s.root = 0; s.K1_eval = 0; s.K2cur = 0; s.Kcur = 0; s.prevJump = INFINITY;
 	s.tnew = 0; s.it = 1; s.phase = 0; s.active = true; s.converged = false;
+	s.want_k = false; s.k_ok = false;
 	(void)g_pos_lb; (void)g_neg_ub;
 }
 
@@ -53,14 +57,21 @@ __device__ __forceinline__ void root_step(RootState &s, double NAsigma)
 	if (!isfinite(tnew)) { s.active = false; return; }
 	if (fabs(tnew - s.t) < SPA_TOL) { s.converged = true; s.active = false; return; }
 	s.tnew = tnew; s.phase = 1; s.active = true;
+	// Newton converges quadratically: if the step after this one is predicted to fall under
+	// the tolerance, this evaluation is the last and its point becomes the root, so Korg is
+	// wanted with it (a wrong guess only costs time: spa3_korg covers the rest)
+	const double st = fabs(tnew - s.t);
+	s.want_k = st * st < 8.0 * SPA_TOL * fmax(fabs(tnew), 1e-3);
 }
 
 // consume the sums evaluated at s.tnew, SPATest.cpp:152,166-181
-__device__ __forceinline__ void root_feed(RootState &s, double K1s, double K2s, double NAmu, double NAsigma)
+__device__ __forceinline__ void root_feed(RootState &s, double K1s, double K2s, double NAmu, double NAsigma,
+	double Ks = 0.0, bool k_valid = false)
 {
 	if (s.phase == 0) {
 		s.K1_eval = (K1s - s.q) + NAmu + NAsigma * s.t;
 		s.K2cur = K2s;
+		s.Kcur = Ks; s.k_ok = k_valid;
 		root_step(s, NAsigma);
 		return;
 	}
@@ -70,6 +81,7 @@ __device__ __forceinline__ void root_feed(RootState &s, double K1s, double K2s, 
 			s.tnew = s.t + d_sign(newK1 - s.K1_eval) * s.prevJump * 0.5;
 			s.prevJump *= 0.5;
 			s.phase = 2;          // re-evaluate at the bisected point
+			s.want_k = false;
 			return;
 		}
 		s.prevJump = fabs(s.tnew - s.t);
@@ -77,6 +89,7 @@ __device__ __forceinline__ void root_feed(RootState &s, double K1s, double K2s, 
 	s.root = s.t = s.tnew;
 	s.K1_eval = newK1;
 	s.K2cur = K2s;
+	s.Kcur = Ks; s.k_ok = k_valid;
 	s.it++;
 	root_step(s, NAsigma);
 }

@@ -5,19 +5,35 @@
 // The per-variant cost of the saddlepoint stage is proportional to the number
 // of carriers (10 ... 320 000 at N = 430K), so "one workgroup per variant"
 // (kern_spa2.h) leaves the chip waiting for the few largest variants.  Here the
-// Newton iteration of ALL flagged variants advances in lock step and each
-// level is one balanced launch over fixed-size chunks of the carrier lists:
+// Newton iteration of ALL flagged variants advances in lock step and every
+// launch is balanced over fixed-size pieces of the carrier lists:
 //
-//   spa3_count/plan/fill/head  carrier lists (adj, mu) of all flagged variants
-//                 appended to one global arena; scalars; cutoff exit; bound
-//                 test for g_pos/g_neg (kern_spa2.h); chunk descriptors
+//   spa3_count  carriers per (variant, 8192-sample segment)
+//   spa3_plan   per variant: scalars that need no carrier pass (m1, q~, the
+//               cutoff exit of SPATest.cpp:319-321),
+//               exclusive scan over its segments, arena allocation
+//   spa3_fill   per (variant, segment): gather X_i, mu_i -> (adj, mu) entries at
+//               their final arena position (ascending sample order), carrier sums
+//   spa3_head   per variant: ordered sums, g_pos/g_neg bound test, the Newton
+//               step at t = 0, chunk descriptors
 //   repeat L times
-//     spa3_pass     one workgroup per chunk: partial K1/K2 sums of the roots
-//                   that are still searching (SPATest.cpp:64,79-80)
-//     spa3_advance  one thread per variant: ordered sum of its chunks' partials
-//                   (deterministic), then getroot_K1_fast's step (root_feed)
-//   spa3_korg     per chunk: sum log(1-mu+mu e^{gt}) at both roots (SPATest.cpp:49)
-//   spa3_finish   per variant: Lugannani-Rice, SE, output row
+//     spa3_pass     per chunk of 4096 carriers: K1, K2, Korg partial sums of the
+//                   roots still searching (SPATest.cpp:49,64,79-80)
+//     spa3_advance  per variant: ordered sum of its chunks' partials, then
+//                   getroot_K1_fast's step (root_feed, kern_spa2.h)
+//   spa3_finish   per variant: Lugannani-Rice (SPATest.cpp:211-230), SE, row
+//
+// Two sweeps over the carrier arena are saved against the plain scheme:
+//  * t = 0 needs no pass: exp(0) = 1 turns the K1/K2 sums into sum g mu and
+//    sum g^2 mu(1-mu), which the extraction has anyway, and Korg(0) = 0.
+//  * Korg rides along in the pass that is predicted to be the last of a search:
+//    getroot_K1_fast returns the LAST EVALUATED point as the root
+//    (SPATest.cpp:161-165,180), so its Korg is then already there; spa3_korg
+//    serves the searches whose end was not predicted.
+// At N = 430K Newton needs ~3 evaluations per root after t = 0, i.e. 3 passes.
+// (Evaluating the first Newton point inside spa3_fill -- it is known from m1 --
+// was tried and lost: that kernel is compaction-shaped, its lanes are poorly
+// filled, and the exp/log work cost 1.7 ms to save a 0.6 ms sweep.)
 //
 // Variants that do not fit the arena, need the exact dense g_pos/g_neg pass, or
 // are still iterating after L levels are appended to fallback lists and handled
@@ -25,10 +41,16 @@
 
 #define SPA3_CHUNK 4096      /* carriers per chunk                     */
 #define SPA3_BLOCK 256
+#define SPA3_MLP 4           /* independent 16-byte loads in flight per thread */
+#define SPA3_SEG 8192        /* samples per extraction segment = 512 dwords */
+#define SPA3_NPART 6         /* doubles per chunk partial: K1a K2a Ka K1b K2b Kb */
+#define SPA3_NSEGP 6         /* doubles per (variant, segment): the carrier sums */
 
 struct SpaHead {
 	int state;        // 0 finished / handed over, 1 searching, 2 both roots converged, 3 not converged
-	int nnz, c0, nchunks;
+	int nnz;          // carriers; < 0: no list (-1 arena full -> spa2, -2 finished in spa3_plan)
+	int c0, nchunks;
+	int pad0_, pad1_;
 	unsigned long long off;     // first list entry in the arena
 	double m1, Tstat, var2, var1, qtilde, qinv, pn_in, NAmu, NAsigma;
 	RootState s1, s2;
@@ -50,19 +72,24 @@ __device__ __forceinline__ void spa_write_row(const SpaRec &r, double Tstat, dou
 	o[7] = converged ? 1.0 : 0.0;
 }
 
+// K1, K2 (SPATest.cpp:64,79-80) and Korg (:49) terms of one carrier at t
+template <bool WITH_K>
+__device__ __forceinline__ void cgf_terms(double g, double m, double t, double &k1, double &k2, double &k0)
+{
+	const double om = 1 - m, mg = m * g, c2 = om * mg * g;
+	const double e = fast_exp(-g * t);
+	const double d = fma(om, e, m);
+	const double rr = isfinite(d) ? fast_rcp(d) : 0.0;
+	k1 = fma(mg, rr, k1);
+	const double tt = c2 * e * rr * rr;
+	if (isfinite(tt)) k2 += tt;
+	// log(1 - m + m e^{gt}) = g t + log((1-m) e^{-gt} + m): reuses the exponential;
+	// when e^{-gt} overflows the reference's own form is evaluated instead
+	if (WITH_K) k0 += isfinite(d) ? fma(g, t, fast_log(d)) : fast_log(fma(m, fast_exp(g * t), om));
+}
+
 // counters: [0] n_spa [1] n_valid [2] n_dense_fallback [3] n_spa2_fallback
 //           [4] chunk cursor [6] number of valid chunk descriptors
-//
-// Extraction is split so that every launch is balanced over (variant, segment)
-// work items, a segment being SPA3_SEG consecutive samples of one flagged row:
-//   spa3_count  carriers per (variant, segment)
-//   spa3_plan   per variant: exclusive scan over its segments, arena allocation
-//   spa3_fill   per (variant, segment): gather X_i, mu_i -> (adj, mu) entries at
-//               their final position (ascending sample order), partial sums
-//   spa3_head   per variant: ordered sum of the partials, scalars, cutoff exit,
-//               g_pos/g_neg bound test, root_begin, chunk descriptors
-
-#define SPA3_SEG 8192        /* samples per extraction segment = 512 dwords */
 
 __global__ void __launch_bounds__(256)
 spa3_count(const uint8_t *__restrict__ packed, size_t bpv, int N, int nseg,
@@ -70,15 +97,14 @@ spa3_count(const uint8_t *__restrict__ packed, size_t bpv, int N, int nseg,
 {
 	__shared__ int shi[4];
 	const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-	const int nitem = counters[0] * nseg;
-	const int ndw = (N + 15) >> 4;
 	const int nflag = counters[0];
+	const int nitem = nflag * nseg;
+	const int ndw = (N + 15) >> 4;
 	for (int wi = blockIdx.x; wi < nitem; wi += gridDim.x) {
 		const int seg = wi / nflag, v = wi - seg * nflag;   // segment-major order
 		const int it = v * nseg + seg;
-		const int minus = recs[v].minus;
 		const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (size_t)recs[v].j * bpv);
-		const uint32_t zx = minus ? 0xAAAAAAAAu : 0u;
+		const uint32_t zx = recs[v].minus ? 0xAAAAAAAAu : 0u;
 		int cnt = 0;
 #pragma unroll
 		for (int u = 0; u < 2; u++) {
@@ -94,23 +120,51 @@ spa3_count(const uint8_t *__restrict__ packed, size_t bpv, int N, int nseg,
 	}
 }
 
+template <int K>
 __global__ void __launch_bounds__(256)
-spa3_plan(int nseg, const SpaRec *__restrict__ recs, int *__restrict__ counters,
+spa3_plan(DevModel md, int nseg, const SpaRec *__restrict__ recs, int *__restrict__ counters,
 	unsigned long long *__restrict__ cursor, unsigned long long arena_cap, int *__restrict__ segcnt,
-	SpaHead *__restrict__ heads, int *__restrict__ fb_spa2)
+	SpaHead *__restrict__ heads, int *__restrict__ fb_spa2, double *__restrict__ out8)
 {
 	const int v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= counters[0]) return;
+	const SpaRec r = recs[v];
+	SpaHead h;
+	h.state = 0; h.c0 = 0; h.nchunks = 0; h.pad0_ = h.pad1_ = 0; h.off = 0;
+	h.m1 = h.qtilde = h.qinv = h.pn_in = h.NAmu = h.NAsigma = 0;
+	const double inv = 1 / sqrt(r.AC2);
+	h.Tstat = r.S * inv;                       // q - m1, saige_main.cpp:380
+	h.var2 = r.var2 / r.AC2;                   // :378
+	h.var1 = h.var2 * md.r;                    // :379
+	bool done = false;
+	if (r.has_gmu) {
+		double xmu_c = 0;
+#pragma unroll
+		for (int a = 0; a < K; a++) xmu_c = fma(md.Xmu[a], r.c[a], xmu_c);
+		h.m1 = (r.sum_gmu - xmu_c) * inv;
+		h.qtilde = h.Tstat / sqrt(h.var1) * sqrt(h.var2) + h.m1;   // :381
+		const double s = h.qtilde - h.m1;
+		h.qinv = -s + h.m1;
+		h.pn_in = d_pchisq1_upper(s * s / h.var2);
+		if (fabs(h.qtilde - h.m1) / sqrt(h.var2) < 2.0) {
+			spa_write_row(r, h.Tstat, h.var1, h.pn_in, true, out8);   // SPATest.cpp:319-321
+			done = true;
+		}
+	}
 	int run = 0;
 	for (int s = 0; s < nseg; s++) { const int c = segcnt[v * nseg + s]; segcnt[v * nseg + s] = run; run += c; }
-	SpaHead *h = heads + v;
-	h->nnz = run; h->c0 = 0; h->nchunks = 0; h->state = 0;
-	const unsigned long long off = atomicAdd(cursor, (unsigned long long)run);
-	h->off = off;
-	if (off + (unsigned long long)run > arena_cap) {
-		h->nnz = -1;                                    // no list: the per-workgroup kernel takes it
-		fb_spa2[atomicAdd(&counters[3], 1)] = v;
+	h.nnz = run;
+	if (done) {
+		h.nnz = -2;
+	} else {
+		const unsigned long long off = atomicAdd(cursor, (unsigned long long)run);
+		h.off = off;
+		if (off + (unsigned long long)run > arena_cap) {
+			h.nnz = -1;                                    // no list: the per-workgroup kernel takes it
+			fb_spa2[atomicAdd(&counters[3], 1)] = v;
+		}
 	}
+	heads[v] = h;
 }
 
 template <int K>
@@ -121,18 +175,19 @@ spa3_fill(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg,
 {
 	constexpr int BLOCK = 256, NW = BLOCK / WAVE;
 	constexpr int KP = (K + 2) & ~1;
-	__shared__ double sh[8 * NW];
+	__shared__ double sh[SPA3_NSEGP * NW];
 	__shared__ int shi[NW];
 	__shared__ uint32_t qidx[SPA3_SEG];
 	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-	const int nitem = counters[0] * nseg;
-	const int ndw = (N + 15) >> 4;
 	const int nflag = counters[0];
+	const int nitem = nflag * nseg;
+	const int ndw = (N + 15) >> 4;
 	for (int wi = blockIdx.x; wi < nitem; wi += gridDim.x) {
 		// segment-major: workgroups running together gather the same 8192 rows of XM (L2)
 		const int seg = wi / nflag, v = wi - seg * nflag;
 		const int it = v * nseg + seg;
-		if (heads[v].nnz < 0) continue;
+		const SpaHead *hd = heads + v;
+		if (hd->nnz < 0) continue;
 		const SpaRec r = recs[v];
 		const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (size_t)r.j * bpv);
 		const double inv = 1 / sqrt(r.AC2);
@@ -172,8 +227,11 @@ spa3_fill(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg,
 			}
 		}
 		__syncthreads();
-		double2 *lst = arena + heads[v].off + (unsigned long long)segoff[it];
-		double a6[6] = {0, 0, 0, 0, 0, 0};
+		double2 *lst = arena + hd->off + (unsigned long long)segoff[it];
+		// 0 sum mu*G, 1 sum b, 2 sum max(adj,0), 3 sum min(adj,0), 4 sum adj*mu, 5 sum adj^2 mu(1-mu)
+		double a12[SPA3_NSEGP];
+#pragma unroll
+		for (int a = 0; a < SPA3_NSEGP; a++) a12[a] = 0;
 		for (int k = tid; k < total; k += BLOCK) {
 			const uint32_t e = qidx[k];
 			const int i = (int)(e & 0x3FFFFFFFu);
@@ -191,14 +249,14 @@ spa3_fill(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg,
 			const double mui = xv[K];
 			const double adj = (G - b) * inv;
 			lst[k] = make_double2(adj, mui);
-			a6[0] = fma(mui, G, a6[0]);
-			a6[1] += b;
-			if (adj > 0) a6[2] += adj; else a6[3] += adj;
-			a6[4] = fma(adj, mui, a6[4]);
-			a6[5] = fma(adj * adj, mui * (1 - mui), a6[5]);
+			a12[0] = fma(mui, G, a12[0]);
+			a12[1] += b;
+			if (adj > 0) a12[2] += adj; else a12[3] += adj;
+			a12[4] = fma(adj, mui, a12[4]);
+			a12[5] = fma(adj * adj, mui * (1 - mui), a12[5]);
 		}
-		block_sum<6, BLOCK>(a6, sh);
-		if (tid < 6) segpart[(size_t)it * 6 + tid] = a6[tid];
+		block_sum<SPA3_NSEGP, BLOCK>(a12, sh);
+		if (tid < SPA3_NSEGP) segpart[(size_t)it * SPA3_NSEGP + tid] = a12[tid];
 	}
 }
 
@@ -214,31 +272,33 @@ spa3_head(DevModel md, int nseg, const SpaRec *__restrict__ recs, int *__restric
 	SpaHead h = heads[v];
 	if (h.nnz < 0) { heads[v].nnz = 0; return; }
 	const SpaRec r = recs[v];
-	double a6[6] = {0, 0, 0, 0, 0, 0};
+	double a[SPA3_NSEGP];
+#pragma unroll
+	for (int q = 0; q < SPA3_NSEGP; q++) a[q] = 0;
 	for (int s = 0; s < nseg; s++)
 #pragma unroll
-		for (int a = 0; a < 6; a++) a6[a] += segpart[((size_t)v * nseg + s) * 6 + a];
+		for (int q = 0; q < SPA3_NSEGP; q++) a[q] += segpart[((size_t)v * nseg + s) * SPA3_NSEGP + q];
 	const double inv = 1 / sqrt(r.AC2);
 	double xmu_c = 0, xsum_c = 0;
 #pragma unroll
-	for (int a = 0; a < K; a++) { xmu_c = fma(md.Xmu[a], r.c[a], xmu_c); xsum_c = fma(md.Xsum[a], r.c[a], xsum_c); }
+	for (int q = 0; q < K; q++) { xmu_c = fma(md.Xmu[q], r.c[q], xmu_c); xsum_c = fma(md.Xsum[q], r.c[q], xsum_c); }
 	const int nnz = h.nnz;
-	h.m1 = (a6[0] - xmu_c) * inv;
-	h.Tstat = r.S * inv;
-	h.var2 = r.var2 / r.AC2;
-	h.var1 = h.var2 * md.r;
-	h.qtilde = h.Tstat / sqrt(h.var1) * sqrt(h.var2) + h.m1;
-	const double s = h.qtilde - h.m1;
-	h.qinv = -s + h.m1;
-	h.pn_in = d_pchisq1_upper(s * s / h.var2);
-	h.NAmu = h.m1 - a6[4];
-	h.NAsigma = h.var2 - a6[5];
+	if (!r.has_gmu) {
+		// gather score path: m1 only now (carrier sum of mu*G), saige_main.cpp:378-381
+		h.m1 = (a[0] - xmu_c) * inv;
+		h.qtilde = h.Tstat / sqrt(h.var1) * sqrt(h.var2) + h.m1;
+		const double s = h.qtilde - h.m1;
+		h.qinv = -s + h.m1;
+		h.pn_in = d_pchisq1_upper(s * s / h.var2);
+	}
+	h.NAmu = h.m1 - a[4];
+	h.NAsigma = h.var2 - a[5];
 	h.state = 0;
 	if (fabs(h.qtilde - h.m1) / sqrt(h.var2) < 2.0) {
 		spa_write_row(r, h.Tstat, h.var1, h.pn_in, true, out8);   // SPATest.cpp:319-321
 	} else {
-		const double nb = (xsum_c - a6[1]) * inv;
-		const double L = a6[2] + fmax(-nb, 0.0), U = a6[3] + fmin(-nb, 0.0);
+		const double nb = (xsum_c - a[1]) * inv;
+		const double L = a[2] + fmax(-nb, 0.0), U = a[3] + fmin(-nb, 0.0);
 		const double mar = 1e-9 * (fabs(L) + fabs(U) + fabs(h.qtilde) + fabs(h.qinv));
 		if (force_dense || !(h.qtilde < L - mar && h.qtilde > U + mar && h.qinv < L - mar && h.qinv > U + mar)) {
 			fb_dense[atomicAdd(&counters[2], 1)] = v;
@@ -253,10 +313,10 @@ spa3_head(DevModel md, int nseg, const SpaRec *__restrict__ recs, int *__restric
 				h.c0 = c0; h.nchunks = nch;
 				root_begin(h.s1, h.qtilde, L, U);
 				root_begin(h.s2, h.qinv, L, U);
-				// the evaluation at t = 0 needs no pass: exp(0) = 1 turns the K1 and K2
-				// sums (SPATest.cpp:64,79) into sum g mu and sum g^2 mu (1-mu)
-				root_feed(h.s1, a6[4], a6[5], h.NAmu, h.NAsigma);
-				root_feed(h.s2, a6[4], a6[5], h.NAmu, h.NAsigma);
+				// t = 0 needs no pass: exp(0) = 1 turns the K1 and K2 sums into
+				// sum g mu and sum g^2 mu (1-mu), and Korg(0) = 0
+				root_feed(h.s1, a[4], a[5], h.NAmu, h.NAsigma, 0.0, true);
+				root_feed(h.s2, a[4], a[5], h.NAmu, h.NAsigma, 0.0, true);
 				h.state = (h.s1.active || h.s2.active) ? 1 : ((h.s1.converged && h.s2.converged) ? 2 : 3);
 				for (int k = 0; k < nch; k++) { chunks[c0 + k].v = v; chunks[c0 + k].k = k; }
 			}
@@ -265,114 +325,92 @@ spa3_head(DevModel md, int nseg, const SpaRec *__restrict__ recs, int *__restric
 	heads[v] = h;
 }
 
-// one workgroup per chunk; partial[chunk] = {K1(t1), K2(t1), K1(t2), K2(t2)} over its carriers
+// one workgroup per chunk; partial[chunk] = {K1, K2, Korg at t1, K1, K2, Korg at t2}
 __global__ void __launch_bounds__(SPA3_BLOCK)
 spa3_pass(const int *__restrict__ counters, const ChunkDesc *__restrict__ chunks,
-	const SpaHead *__restrict__ heads, const double2 *__restrict__ arena, double4 *__restrict__ partial)
+	const SpaHead *__restrict__ heads, const double2 *__restrict__ arena, double *__restrict__ partial)
 {
-	__shared__ double sh[4 * (SPA3_BLOCK / WAVE)];
+	__shared__ double sh[SPA3_NPART * (SPA3_BLOCK / WAVE)];
 	const int nchunk = counters[6];
 	for (int ci = blockIdx.x; ci < nchunk; ci += gridDim.x) {
 		const ChunkDesc cd = chunks[ci];
 		const SpaHead *h = heads + cd.v;
 		if (h->state != 1) continue;
 		const bool a1 = h->s1.active, a2 = h->s2.active;
+		const bool k1w = h->s1.want_k, k2w = h->s2.want_k;
 		const double t1 = h->s1.tnew, t2 = h->s2.tnew;
 		const int beg = cd.k * SPA3_CHUNK, end = min(h->nnz, beg + SPA3_CHUNK);
 		const double2 *lst = arena + h->off;
-		double v[4] = {0, 0, 0, 0};
-		for (int k0 = beg + threadIdx.x; k0 < end; k0 += 4 * SPA3_BLOCK) {
-			double2 gm4[4];
+		double v[SPA3_NPART] = {0, 0, 0, 0, 0, 0};
+		for (int k0 = beg + threadIdx.x; k0 < end; k0 += SPA3_MLP * SPA3_BLOCK) {
+			double2 gm[SPA3_MLP];
 #pragma unroll
-			for (int j = 0; j < 4; j++) {          // four independent loads in flight
+			for (int j = 0; j < SPA3_MLP; j++) {   // independent loads in flight
 				const int k = k0 + j * SPA3_BLOCK;
-				gm4[j] = (k < end) ? lst[k] : make_double2(0.0, 0.5);   // g = 0 adds exactly 0
+				gm[j] = (k < end) ? lst[k] : make_double2(0.0, 0.5);   // g = 0 adds exactly 0
 			}
 #pragma unroll
-			for (int j = 0; j < 4; j++) {
-				const double g = gm4[j].x, m = gm4[j].y, om = 1 - m;
-				const double mg = m * g, c2 = om * mg * g;
-				if (a1) {
-					const double e = fast_exp(-g * t1);
-					const double d = fma(om, e, m);
-					const double rr = isfinite(d) ? fast_rcp(d) : 0.0;
-					v[0] = fma(mg, rr, v[0]);
-					const double tt = c2 * e * rr * rr;
-					if (isfinite(tt)) v[1] += tt;
-				}
-				if (a2) {
-					const double e = fast_exp(-g * t2);
-					const double d = fma(om, e, m);
-					const double rr = isfinite(d) ? fast_rcp(d) : 0.0;
-					v[2] = fma(mg, rr, v[2]);
-					const double tt = c2 * e * rr * rr;
-					if (isfinite(tt)) v[3] += tt;
-				}
+			for (int j = 0; j < SPA3_MLP; j++) {
+				if (a1) { if (k1w) cgf_terms<true>(gm[j].x, gm[j].y, t1, v[0], v[1], v[2]); else cgf_terms<false>(gm[j].x, gm[j].y, t1, v[0], v[1], v[2]); }
+				if (a2) { if (k2w) cgf_terms<true>(gm[j].x, gm[j].y, t2, v[3], v[4], v[5]); else cgf_terms<false>(gm[j].x, gm[j].y, t2, v[3], v[4], v[5]); }
 			}
 		}
-		block_sum<4, SPA3_BLOCK>(v, sh);
-		if (threadIdx.x == 0) partial[ci] = make_double4(v[0], v[1], v[2], v[3]);
+		block_sum<SPA3_NPART, SPA3_BLOCK>(v, sh);
+		if (threadIdx.x < SPA3_NPART) partial[(size_t)ci * SPA3_NPART + threadIdx.x] = v[threadIdx.x];
 	}
 }
 
 // one thread per flagged variant: consume the partial sums, take the Newton step
 __global__ void __launch_bounds__(256)
-spa3_advance(int *__restrict__ counters, SpaHead *__restrict__ heads, const double4 *__restrict__ partial)
+spa3_advance(int *__restrict__ counters, SpaHead *__restrict__ heads, const double *__restrict__ partial)
 {
 	const int v = blockIdx.x * blockDim.x + threadIdx.x;
 	if (v >= counters[0]) return;
 	SpaHead *h = heads + v;
 	if (h->state != 1) return;
-	double s[4] = {0, 0, 0, 0};
-	for (int k = 0; k < h->nchunks; k++) {
-		const double4 p = partial[h->c0 + k];
-		s[0] += p.x; s[1] += p.y; s[2] += p.z; s[3] += p.w;
-	}
+	double s[SPA3_NPART] = {0, 0, 0, 0, 0, 0};
+	for (int k = 0; k < h->nchunks; k++)
+#pragma unroll
+		for (int q = 0; q < SPA3_NPART; q++) s[q] += partial[(size_t)(h->c0 + k) * SPA3_NPART + q];
 	RootState s1 = h->s1, s2 = h->s2;
-	if (s1.active) root_feed(s1, s[0], s[1], h->NAmu, h->NAsigma);
-	if (s2.active) root_feed(s2, s[2], s[3], h->NAmu, h->NAsigma);
+	if (s1.active) { const bool kv = s1.want_k; root_feed(s1, s[0], s[1], h->NAmu, h->NAsigma, s[2], kv); }
+	if (s2.active) { const bool kv = s2.want_k; root_feed(s2, s[3], s[4], h->NAmu, h->NAsigma, s[5], kv); }
 	h->s1 = s1; h->s2 = s2;
 	if (!s1.active && !s2.active) h->state = (s1.converged && s2.converged) ? 2 : 3;
 }
 
-// Korg partial sums at both roots for variants whose two searches converged
+// Korg at the root for the searches that ended at a point evaluated without it
+// (the guess in root_step was wrong); partial[chunk] = {.., .., Ka, .., .., Kb}
 __global__ void __launch_bounds__(SPA3_BLOCK)
 spa3_korg(const int *__restrict__ counters, const ChunkDesc *__restrict__ chunks,
-	const SpaHead *__restrict__ heads, const double2 *__restrict__ arena, double4 *__restrict__ partial)
+	const SpaHead *__restrict__ heads, const double2 *__restrict__ arena, double *__restrict__ partial)
 {
 	__shared__ double sh[2 * (SPA3_BLOCK / WAVE)];
 	const int nchunk = counters[6];
 	for (int ci = blockIdx.x; ci < nchunk; ci += gridDim.x) {
 		const ChunkDesc cd = chunks[ci];
 		const SpaHead *h = heads + cd.v;
-		if (h->state != 2) continue;
+		if (h->state != 2 || (h->s1.k_ok && h->s2.k_ok)) continue;
+		const bool n1 = !h->s1.k_ok, n2 = !h->s2.k_ok;
 		const double t1 = h->s1.root, t2 = h->s2.root;
 		const int beg = cd.k * SPA3_CHUNK, end = min(h->nnz, beg + SPA3_CHUNK);
 		const double2 *lst = arena + h->off;
 		double v[2] = {0, 0};
-		for (int k0 = beg + threadIdx.x; k0 < end; k0 += 4 * SPA3_BLOCK) {
-			double2 gm4[4];
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				const int k = k0 + j * SPA3_BLOCK;
-				gm4[j] = (k < end) ? lst[k] : make_double2(0.0, 0.5);   // log(1) = 0
-			}
-#pragma unroll
-			for (int j = 0; j < 4; j++) {
-				const double g = gm4[j].x, m = gm4[j].y, om = 1 - m;
-				v[0] += fast_log(fma(m, fast_exp(g * t1), om));
-				v[1] += fast_log(fma(m, fast_exp(g * t2), om));
-			}
+		for (int k = beg + threadIdx.x; k < end; k += SPA3_BLOCK) {
+			const double2 gm = lst[k];
+			const double g = gm.x, m = gm.y, om = 1 - m;
+			if (n1) v[0] += fast_log(fma(m, fast_exp(g * t1), om));
+			if (n2) v[1] += fast_log(fma(m, fast_exp(g * t2), om));
 		}
 		block_sum<2, SPA3_BLOCK>(v, sh);
-		if (threadIdx.x == 0) partial[ci] = make_double4(v[0], v[1], 0, 0);
+		if (threadIdx.x == 0) { partial[(size_t)ci * SPA3_NPART + 2] = v[0]; partial[(size_t)ci * SPA3_NPART + 5] = v[1]; }
 	}
 }
 
 // one thread per flagged variant: tail probabilities and the output row;
 // variants still searching go to the spa2 fallback list
 __global__ void __launch_bounds__(256)
-spa3_finish(int *__restrict__ counters, SpaHead *__restrict__ heads, const double4 *__restrict__ partial,
+spa3_finish(int *__restrict__ counters, SpaHead *__restrict__ heads, const double *__restrict__ partial,
 	const SpaRec *__restrict__ recs, int *__restrict__ fb_spa2, double *__restrict__ out8)
 {
 	const int v = blockIdx.x * blockDim.x + threadIdx.x;
@@ -384,10 +422,18 @@ spa3_finish(int *__restrict__ counters, SpaHead *__restrict__ heads, const doubl
 	double pval;
 	bool converged = true;
 	if (h->state == 2) {
-		double k1 = 0, k2 = 0;
-		for (int k = 0; k < h->nchunks; k++) { const double4 p = partial[h->c0 + k]; k1 += p.x; k2 += p.y; }
-		const double p1 = lugannani_rice(h->s1.root, k1, h->s1.K2cur, h->qtilde, h->NAmu, h->NAsigma);
-		const double p2 = lugannani_rice(h->s2.root, k2, h->s2.K2cur, h->qinv, h->NAmu, h->NAsigma);
+		double ka = h->s1.Kcur, kb = h->s2.Kcur;
+		if (!h->s1.k_ok || !h->s2.k_ok) {      // sums of spa3_korg
+			double sa = 0, sb = 0;
+			for (int k = 0; k < h->nchunks; k++) {
+				sa += partial[(size_t)(h->c0 + k) * SPA3_NPART + 2];
+				sb += partial[(size_t)(h->c0 + k) * SPA3_NPART + 5];
+			}
+			if (!h->s1.k_ok) ka = sa;
+			if (!h->s2.k_ok) kb = sb;
+		}
+		const double p1 = lugannani_rice(h->s1.root, ka, h->s1.K2cur, h->qtilde, h->NAmu, h->NAsigma);
+		const double p2 = lugannani_rice(h->s2.root, kb, h->s2.K2cur, h->qinv, h->NAmu, h->NAsigma);
 		pval = fabs(p1) + fabs(p2);
 		if (pval != 0 && h->pn_in / pval > 1000) pval = h->pn_in;   // SPATest.cpp:368-371
 	} else {

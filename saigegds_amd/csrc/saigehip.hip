@@ -81,7 +81,7 @@ struct sgx_handle {
 	SpaHead *heads = nullptr;
 	double2 *arena = nullptr; unsigned long long arena_cap = 0;
 	unsigned long long *cursor = nullptr;
-	ChunkDesc *chunks = nullptr; double4 *partial = nullptr; int chunk_cap = 0;
+	ChunkDesc *chunks = nullptr; double *partial = nullptr; int chunk_cap = 0;
 	int *segcnt = nullptr; double *segpart = nullptr; int nseg = 0;
 	int spa_levels = 12;
 	unsigned long long arena_limit = 0;   // test hook: pretend the arena is this small (0 = real size)
@@ -194,25 +194,27 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 	std::vector<int8_t> Fl;
 	if (P <= MF_MAXP && (double)N * 384.0 < 2147483647.0) {
 		MfTab &tb = h->mf;
-		const int ncolv = MF_NLIMB * P + 1;
+		const int PE = P + 1;                       // score columns + mu
+		const int ncolv = MF_NLIMB * PE + 1;
 		tb.nbfv = (ncolv + 15) / 16;
 		tb.ncol = 16 * (tb.nbfv + 1);
 		tb.nacc = tb.ncol + 16 * tb.nbfv;
-		tb.col_ones = MF_NLIMB * P;
+		tb.col_ones = MF_NLIMB * PE;
 		tb.col_b1 = 16 * tb.nbfv;
 		const int ngrp = (N + 15) / 16;
 		tb.ntile = (ngrp + 15) / 16;
 		const size_t ngrp_pad = (size_t)tb.ntile * 16;
 		Fl.assign(ngrp_pad * tb.ncol * 16, 0);
-		for (int c = 0; c < P; c++) {
+		for (int c = 0; c < PE; c++) {
+			auto Fc = [&](int i) { return c < P ? F[(size_t)i * P + c] : m->mu[i]; };
 			double mx = 0;
-			for (int i = 0; i < N; i++) mx = std::max(mx, std::fabs(F[(size_t)i * P + c]));
+			for (int i = 0; i < N; i++) mx = std::max(mx, std::fabs(Fc(i)));
 			int ex = 0;
 			if (mx > 0) (void)std::frexp(mx, &ex);
 			tb.escale[c] = 54 - ex;
 			__int128 tot = 0;
 			for (int i = 0; i < N; i++) {
-				long long q = std::llrint(std::ldexp(F[(size_t)i * P + c], tb.escale[c]));
+				long long q = std::llrint(std::ldexp(Fc(i), tb.escale[c]));
 				tot += q;
 				int8_t *base = &Fl[((size_t)(i / 16) * tb.ncol) * 16 + (i % 16)];
 				long long rem = q;
@@ -315,13 +317,13 @@ static int ensure_recs(sgx_handle *h, size_t n)
 		h->segcnt = nullptr; h->segpart = nullptr;
 		h->nseg = (h->md.N + SPA3_SEG - 1) / SPA3_SEG;
 		HIPCHK(hipMalloc((void **)&h->segcnt, n * (size_t)h->nseg * sizeof(int)));
-		HIPCHK(hipMalloc((void **)&h->segpart, n * (size_t)h->nseg * 6 * sizeof(double)));
+		HIPCHK(hipMalloc((void **)&h->segpart, n * (size_t)h->nseg * SPA3_NSEGP * sizeof(double)));
 		h->fb_spa2 = nullptr; h->heads = nullptr; h->chunks = nullptr; h->partial = nullptr;
 		h->chunk_cap = (int)std::min<unsigned long long>(0x7fffffffull, h->arena_cap / SPA3_CHUNK + n);
 		HIPCHK(hipMalloc((void **)&h->fb_spa2, n * sizeof(int)));
 		HIPCHK(hipMalloc((void **)&h->heads, n * sizeof(SpaHead)));
 		HIPCHK(hipMalloc((void **)&h->chunks, (size_t)h->chunk_cap * sizeof(ChunkDesc)));
-		HIPCHK(hipMalloc((void **)&h->partial, (size_t)h->chunk_cap * sizeof(double4)));
+		HIPCHK(hipMalloc((void **)&h->partial, (size_t)h->chunk_cap * SPA3_NPART * sizeof(double)));
 	}
 	if (h->mf_ok) {
 		if (h->mf_acc) HIPCHK(hipFree(h->mf_acc));
@@ -365,8 +367,8 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	hipLaunchKernelGGL((score_mfma_epilogue<PP>), dim3((unsigned)((M + 255) / 256)), dim3(256), \
 		0, st, (int)M, md, tb, h->mf_acc, h->recs, h->counters, out8, valid);
 		switch (P) {
-		case 4: MFCASE(2, 4) break;
-		case 6: MFCASE(3, 6) break;
+		case 4: MFCASE(3, 4) break;
+		case 6: MFCASE(4, 6) break;
 		case 8: MFCASE(4, 8) break;
 		case 10: MFCASE(5, 10) break;
 		default: return fail(SGX_EINVAL, "MFMA score path: unsupported P=%d", P);
@@ -407,10 +409,10 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			const dim3 gitem((unsigned)(h->n_cu * 16));                                      \
 			hipLaunchKernelGGL(spa3_count, gitem, dim3(256), 0, st, (const uint8_t *)rows,   \
 				row_bytes, md.N, h->nseg, h->recs, h->counters, h->segcnt);                  \
-			hipLaunchKernelGGL(spa3_plan, g256, dim3(256), 0, st, h->nseg, h->recs,          \
+			hipLaunchKernelGGL((spa3_plan<KK>), g256, dim3(256), 0, st, md, h->nseg, h->recs,\
 				h->counters, h->cursor,                                                      \
 				(h->arena_limit ? std::min(h->arena_limit, h->arena_cap) : h->arena_cap),    \
-				h->segcnt, h->heads, h->fb_spa2);      \
+				h->segcnt, h->heads, h->fb_spa2, out8);      \
 			hipLaunchKernelGGL((spa3_fill<KK>), gitem, dim3(256), 0, st,                     \
 				(const uint8_t *)rows, row_bytes, md, h->nseg, h->recs, h->counters,         \
 				h->segcnt, h->heads, h->arena, h->segpart);                                  \
