@@ -159,6 +159,23 @@ int sgx_synth_2bit_dev(sgx_handle *h, uint8_t *packed_dev, size_t bytes_per_vari
 	int32_t n_samp, size_t n_variants, uint64_t first_variant, uint64_t seed,
 	const uint32_t *thr_dev);
 
+/* Null-model fit: implicit GRM on 2-bit packed genotypes ------------------------
+ * The operator inside seqFitNullGLMM_SPA()'s AI-REML/PCG loop:
+ *   sgx_grm_init       <- saige_store_2b_geno    src/saige_fitnull.cpp:159-230
+ *   sgx_grm_diag       <- buf_diag_grm           :205-227
+ *   sgx_grm_crossprod  <- get_crossprod_b_grm    :435-536   out = G'(G b)/M
+ *   sgx_grm_pcg        <- PCG_diag_sigma         :581-614   (tau0 diag(1/w) + tau1 GRM) x = b
+ * packed: n_markers rows of bytes_per_marker bytes, 4 samples per byte (as above);
+ * vectors are host arrays of n_samp doubles. */
+typedef struct sgx_grm sgx_grm;
+int  sgx_grm_init(const uint8_t *packed, size_t bytes_per_marker, int32_t n_samp,
+	size_t n_markers, int device, sgx_grm **out);
+void sgx_grm_free(sgx_grm *g);
+int  sgx_grm_diag(sgx_grm *g, double *diag_out);
+int  sgx_grm_crossprod(sgx_grm *g, const double *b, double *out);
+int  sgx_grm_pcg(sgx_grm *g, const double *w, const double *tau, const double *b,
+	int maxiter, double tol, double *x_out, int *iters_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,5 +3,5 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
 import this package.  See oracle/saige_oracle.c for scope and citations.
 """
-from .oracle import (Oracle, OracleTrace, build_oracle, pchisq1_upper, pnorm,  # noqa: F401
-                     qnorm, saddle_prob_fast)
+from .oracle import (GrmOracle, Oracle, OracleTrace, build_oracle, pchisq1_upper,  # noqa: F401
+                     pnorm, qnorm, saddle_prob_fast)

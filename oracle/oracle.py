@@ -24,9 +24,9 @@ class OracleTrace(C.Structure):
 
 
 def build_oracle(force: bool = False) -> str:
-    src = os.path.join(_HERE, "saige_oracle.c")
+    mt = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("saige_oracle.c", "grm_oracle.c", "saige_oracle.h"))
     for so in (_SO, _SO_LD):
-        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        if force or not os.path.exists(so) or os.path.getmtime(so) < mt:
             subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(so)],
                                   stdout=subprocess.DEVNULL)
     return _SO
@@ -68,6 +68,13 @@ def _bind(L):
     L.orc_saddle_prob_fast.argtypes = [
         C.c_double, C.c_double, C.c_double, C.c_size_t, dp, dp, C.c_size_t,
         C.POINTER(C.c_int), C.c_double, C.POINTER(C.c_int), dp, dp, C.POINTER(OracleTrace)]
+    L.orc_grm_new.restype = C.c_void_p
+    L.orc_grm_new.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_size_t]
+    L.orc_grm_free.argtypes = [C.c_void_p]
+    L.orc_grm_diag.argtypes = [C.c_void_p, dp]
+    L.orc_grm_crossprod.argtypes = [C.c_void_p, dp, dp]
+    L.orc_grm_pcg.restype = C.c_int
+    L.orc_grm_pcg.argtypes = [C.c_void_p, dp, dp, dp, C.c_int, C.c_double, dp]
     return L
 
 
@@ -156,3 +163,43 @@ class Oracle:
         self._L.orc_scan_u8(self._h, dosage.ctypes.data, m, _dp(out),
                             valid.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(self.trace))
         return out, valid
+
+
+class GrmOracle:
+    """Implicit GRM of the null-model fit, CPU restatement (grm_oracle.c)."""
+
+    def __init__(self, packed: np.ndarray, n_samp: int):
+        self._L = _load()
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        self.n, self.m = int(n_samp), packed.shape[0]
+        self._h = self._L.orc_grm_new(packed.ctypes.data, packed.shape[1], self.n, self.m)
+
+    def close(self):
+        if self._h:
+            self._L.orc_grm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def diag(self):
+        out = np.empty(self.n)
+        self._L.orc_grm_diag(self._h, _dp(out))
+        return out
+
+    def crossprod(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        out = np.empty(self.n)
+        self._L.orc_grm_crossprod(self._h, _dp(b), _dp(out))
+        return out
+
+    def pcg(self, w, tau, b, maxiter=500, tol=1e-5):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        x = np.empty(self.n)
+        it = self._L.orc_grm_pcg(self._h, _dp(w), _dp(tau), _dp(b), int(maxiter), float(tol), _dp(x))
+        return x, int(it)

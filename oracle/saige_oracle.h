@@ -42,6 +42,15 @@ int orc_scan_u8(orc_model *M, const uint8_t *dosage, size_t n_variants,
 int orc_scan_2bit(orc_model *M, const uint8_t *packed, size_t bytes_per_variant,
 	size_t n_variants, double *out8, uint8_t *valid, orc_trace *tr);
 
+/* implicit-GRM operator of the null-model fit (grm_oracle.c) */
+typedef struct orc_grm orc_grm;
+orc_grm *orc_grm_new(const uint8_t *packed, size_t bpv, int n_samp, size_t n_markers);
+void orc_grm_free(orc_grm *G);
+void orc_grm_diag(const orc_grm *G, double *out);
+void orc_grm_crossprod(orc_grm *G, const double *b, double *out);
+int orc_grm_pcg(orc_grm *G, const double *w, const double *tau, const double *b,
+	int maxiter, double tol, double *x);
+
 #ifdef __cplusplus
 }
 #endif

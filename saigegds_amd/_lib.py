@@ -17,6 +17,7 @@ EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
     "sgx_set_thresholds", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64",
     "sgx_sync", "sgx_get_stats", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
+    "sgx_grm_init", "sgx_grm_free", "sgx_grm_diag", "sgx_grm_crossprod", "sgx_grm_pcg",
 )
 
 
@@ -112,6 +113,16 @@ def load():
     L.sgx_row_stride.argtypes = [C.c_int32]
     L.sgx_synth_2bit_dev.restype = C.c_int
     L.sgx_synth_2bit_dev.argtypes = [vp, vp, sz, C.c_int32, sz, C.c_uint64, C.c_uint64, vp]
+    L.sgx_grm_init.restype = C.c_int
+    L.sgx_grm_init.argtypes = [vp, sz, C.c_int32, sz, C.c_int, C.POINTER(vp)]
+    L.sgx_grm_free.restype = None
+    L.sgx_grm_free.argtypes = [vp]
+    L.sgx_grm_diag.restype = C.c_int
+    L.sgx_grm_diag.argtypes = [vp, vp]
+    L.sgx_grm_crossprod.restype = C.c_int
+    L.sgx_grm_crossprod.argtypes = [vp, vp, vp]
+    L.sgx_grm_pcg.restype = C.c_int
+    L.sgx_grm_pcg.argtypes = [vp, vp, vp, vp, C.c_int, dp, vp, C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -220,3 +231,60 @@ class Scanner:
 
     def set_thresholds(self, maf, mac, missing, spa_pval):
         check(self._L.sgx_set_thresholds(self._h, maf, mac, missing, spa_pval))
+
+
+class GrmOperator:
+    """Implicit GRM of the null-model fit on one GPU (``sgx_grm``): the operator
+    behind ``saige_store_2b_geno`` / ``get_crossprod_b_grm`` / ``PCG_diag_sigma``
+    (reference src/saige_fitnull.cpp:159-230, 435-536, 581-614)."""
+
+    def __init__(self, packed: np.ndarray, n_samp: int, device: int = 0):
+        L = load()
+        self._L = L
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        if packed.ndim != 2:
+            raise ValueError("packed genotypes must be [n_markers, bytes_per_marker]")
+        self.n, self.m = int(n_samp), int(packed.shape[0])
+        h = C.c_void_p()
+        check(L.sgx_grm_init(packed.ctypes.data, packed.shape[1], self.n, self.m, int(device), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sgx_grm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def diag(self) -> np.ndarray:
+        out = np.empty(self.n, dtype=np.float64)
+        check(self._L.sgx_grm_diag(self._h, out.ctypes.data))
+        return out
+
+    def crossprod(self, b: np.ndarray) -> np.ndarray:
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        if b.shape != (self.n,):
+            raise ValueError("b must have one entry per sample")
+        out = np.empty(self.n, dtype=np.float64)
+        check(self._L.sgx_grm_crossprod(self._h, b.ctypes.data, out.ctypes.data))
+        return out
+
+    def pcg(self, w: np.ndarray, tau, b: np.ndarray, maxiter: int = 500, tol: float = 1e-5):
+        w = np.ascontiguousarray(w, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        tau = np.ascontiguousarray(tau, dtype=np.float64)
+        x = np.empty(self.n, dtype=np.float64)
+        it = C.c_int(0)
+        check(self._L.sgx_grm_pcg(self._h, w.ctypes.data, tau.ctypes.data, b.ctypes.data, int(maxiter),
+                                  float(tol), x.ctypes.data, C.byref(it)))
+        return x, int(it.value)

@@ -71,12 +71,14 @@ __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 // [ncol, ncol + 16 nbfv) the same value columns summed over MISSING samples only
 // (plane [code == 3]); that plane is multiplied only in fragments that contain
 // a missing code, which a wave decides with one ballot.
-template <int NBFV, int P>
+// HAS_B1 = false drops the bit-1 plane and its fragment (the implicit-GRM products
+// of kern_grm.h only need the code plane and the missing plane).
+template <int NBFV, bool HAS_B1>
 __global__ void __launch_bounds__(WAVE * MF_WAVES, 2)
 score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab tb,
 	int tiles_per_split, int *__restrict__ accbuf)
 {
-	constexpr int NBF = NBFV + 1;
+	constexpr int NBF = NBFV + (HAS_B1 ? 1 : 0);
 	constexpr int NCOL = 16 * NBF;
 	constexpr int NACC = NCOL + 16 * NBFV;
 	constexpr int TILE_BYTES = 16 * NCOL * 16;
@@ -146,7 +148,7 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 #pragma unroll
 				for (int b = 0; b < NBFV; b++)
 					acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(val, bfrag[b], acc[f][b], 0, 0, 0);
-				acc[f][NBFV] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, bfrag[NBFV], acc[f][NBFV], 0, 0, 0);
+				if (HAS_B1) acc[f][NBF - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, bfrag[NBF - 1], acc[f][NBF - 1], 0, 0, 0);
 				// samples beyond N have all-zero limbs, so stray codes there add nothing
 				if (__ballot((w & (w >> 1) & LO_MASK) != 0)) {
 					saw_missing = true;

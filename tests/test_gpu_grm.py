@@ -1,0 +1,66 @@
+"""GPU parity of the null-model operator: implicit GRM on
+2-bit genotypes, against the CPU restatement of src/saige_fitnull.cpp:159-230,
+435-536, 581-614 (oracle/grm_oracle.c; parity unpinned by reference vectors)."""
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(300, method="thread")]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _torch_first():
+    import torch
+    assert torch.cuda.is_available()
+    yield
+
+
+def _case(n, m, seed, miss=5e-3):
+    from saigegds_amd import synth
+    thr = synth.variant_thresholds(0, m, seed, log10_maf=(-2.0, -0.3), flip_frac=0.2, miss_rate=miss)
+    packed = synth.synth_packed(n, 0, m, seed, thr)
+    packed[3] = 0                      # a monomorphic marker: inv = 0 (saige_fitnull.cpp:195-197)
+    packed[7, : (n + 3) // 4] = 0xFF   # an all-missing marker: af = NaN -> 0
+    if n % 4:                          # padding codes beyond N must not count
+        packed[7, (n + 3) // 4 - 1] &= (1 << (2 * (n % 4))) - 1
+        packed[:, (n + 3) // 4 - 1] &= (1 << (2 * (n % 4))) - 1
+    return packed
+
+
+@pytest.mark.parametrize("n,m", [(1000, 3000), (3001, 1111), (777, 260)])
+def test_grm_operator_matches_oracle(n, m):
+    from oracle import GrmOracle
+    from saigegds_amd._lib import GrmOperator
+    packed = _case(n, m, seed=n + m)
+    orc = GrmOracle(packed, n)
+    rng = np.random.default_rng(5)
+    with GrmOperator(packed, n) as op:
+        np.testing.assert_allclose(op.diag(), orc.diag(), rtol=1e-12, atol=0)
+        for scale in (1.0, 1e-6, 3e7):
+            b = rng.standard_normal(n) * scale
+            ref = orc.crossprod(b)
+            out = op.crossprod(b)
+            assert np.max(np.abs(out - ref)) <= 1e-11 * np.max(np.abs(ref))
+        # +-1 vectors of the Hutchinson trace estimator (saige_fitnull.cpp:649)
+        u = 2.0 * rng.integers(0, 2, n) - 1
+        assert np.max(np.abs(op.crossprod(u) - orc.crossprod(u))) <= 1e-11 * np.max(np.abs(orc.crossprod(u)))
+
+
+def test_pcg_matches_oracle(grm1k):
+    """PCG_diag_sigma with the reference's defaults tolPCG=1e-5, maxiterPCG=500."""
+    from oracle import GrmOracle
+    from saigegds_amd._lib import GrmOperator
+    n, packed = 1000, grm1k["packed"][:4000]
+    rng = np.random.default_rng(9)
+    mu = rng.uniform(0.02, 0.4, n)
+    w = mu * (1 - mu)
+    b = rng.standard_normal(n)
+    orc = GrmOracle(packed, n)
+    with GrmOperator(packed, n) as op:
+        for tau in ([1.0, 0.33220629], [1.0, 0.0], [0.97, 2.5]):
+            xr, itr = orc.pcg(w, tau, b, 500, 1e-5)
+            xg, itg = op.pcg(w, tau, b, 500, 1e-5)
+            assert itg == itr, (tau, itg, itr)
+            np.testing.assert_allclose(xg, xr, rtol=1e-8, atol=1e-10 * np.max(np.abs(xr)))
+        # iteration cap honoured
+        _, itg = op.pcg(w, [1.0, 5.0], b, 3, 1e-30)
+        assert itg == 3
