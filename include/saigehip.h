@@ -170,6 +170,11 @@ int sgx_synth_2bit_dev(sgx_handle *h, uint8_t *packed_dev, size_t bytes_per_vari
 typedef struct sgx_grm sgx_grm;
 int  sgx_grm_init(const uint8_t *packed, size_t bytes_per_marker, int32_t n_samp,
 	size_t n_markers, int device, sgx_grm **out);
+/* packed_dev in this GPU's HBM (copied); b_dev/out_dev device vectors */
+int  sgx_grm_init_dev(const uint8_t *packed_dev, size_t bytes_per_marker, int32_t n_samp,
+	size_t n_markers, int device, sgx_grm **out);
+int  sgx_grm_crossprod_dev(sgx_grm *g, const double *b_dev, double *out_dev);
+int  sgx_grm_sync(sgx_grm *g);
 void sgx_grm_free(sgx_grm *g);
 int  sgx_grm_diag(sgx_grm *g, double *diag_out);
 int  sgx_grm_crossprod(sgx_grm *g, const double *b, double *out);

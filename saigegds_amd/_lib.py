@@ -17,7 +17,7 @@ EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
     "sgx_set_thresholds", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64",
     "sgx_sync", "sgx_get_stats", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
-    "sgx_grm_init", "sgx_grm_free", "sgx_grm_diag", "sgx_grm_crossprod", "sgx_grm_pcg",
+    "sgx_grm_init", "sgx_grm_init_dev", "sgx_grm_crossprod_dev", "sgx_grm_sync", "sgx_grm_free", "sgx_grm_diag", "sgx_grm_crossprod", "sgx_grm_pcg",
 )
 
 
@@ -115,6 +115,12 @@ def load():
     L.sgx_synth_2bit_dev.argtypes = [vp, vp, sz, C.c_int32, sz, C.c_uint64, C.c_uint64, vp]
     L.sgx_grm_init.restype = C.c_int
     L.sgx_grm_init.argtypes = [vp, sz, C.c_int32, sz, C.c_int, C.POINTER(vp)]
+    L.sgx_grm_init_dev.restype = C.c_int
+    L.sgx_grm_init_dev.argtypes = [vp, sz, C.c_int32, sz, C.c_int, C.POINTER(vp)]
+    L.sgx_grm_crossprod_dev.restype = C.c_int
+    L.sgx_grm_crossprod_dev.argtypes = [vp, vp, vp]
+    L.sgx_grm_sync.restype = C.c_int
+    L.sgx_grm_sync.argtypes = [vp]
     L.sgx_grm_free.restype = None
     L.sgx_grm_free.argtypes = [vp]
     L.sgx_grm_diag.restype = C.c_int
@@ -238,16 +244,30 @@ class GrmOperator:
     behind ``saige_store_2b_geno`` / ``get_crossprod_b_grm`` / ``PCG_diag_sigma``
     (reference src/saige_fitnull.cpp:159-230, 435-536, 581-614)."""
 
-    def __init__(self, packed: np.ndarray, n_samp: int, device: int = 0):
+    def __init__(self, packed, n_samp: int, device: int = 0, dev_ptr: int = 0, n_markers: int = 0,
+                 bytes_per_marker: int = 0):
+        """packed: numpy [n_markers, bytes_per_marker]; or dev_ptr/n_markers/bytes_per_marker
+        for a matrix already in this GPU's memory."""
         L = load()
         self._L = L
-        packed = np.ascontiguousarray(packed, dtype=np.uint8)
-        if packed.ndim != 2:
-            raise ValueError("packed genotypes must be [n_markers, bytes_per_marker]")
-        self.n, self.m = int(n_samp), int(packed.shape[0])
         h = C.c_void_p()
-        check(L.sgx_grm_init(packed.ctypes.data, packed.shape[1], self.n, self.m, int(device), C.byref(h)))
+        self.n = int(n_samp)
+        if dev_ptr:
+            self.m = int(n_markers)
+            check(L.sgx_grm_init_dev(dev_ptr, int(bytes_per_marker), self.n, self.m, int(device), C.byref(h)))
+        else:
+            packed = np.ascontiguousarray(packed, dtype=np.uint8)
+            if packed.ndim != 2:
+                raise ValueError("packed genotypes must be [n_markers, bytes_per_marker]")
+            self.m = int(packed.shape[0])
+            check(L.sgx_grm_init(packed.ctypes.data, packed.shape[1], self.n, self.m, int(device), C.byref(h)))
         self._h = h
+
+    def crossprod_dev(self, b_ptr: int, out_ptr: int):
+        check(self._L.sgx_grm_crossprod_dev(self._h, b_ptr, out_ptr))
+
+    def sync(self):
+        check(self._L.sgx_grm_sync(self._h))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -778,8 +778,24 @@ extern "C" void sgx_grm_free(sgx_grm *g)
 
 // saige_store_2b_geno (saige_fitnull.cpp:159-230): packed = n_markers rows of
 // bytes_per_marker bytes (>= ceil(N/4)), 2-bit codes 0/1/2 = allele count, 3 = missing
+static int grm_init_impl(const uint8_t *packed, size_t bytes_per_marker, int32_t n_samp,
+	size_t n_markers, int device, sgx_grm **out, hipMemcpyKind kind);
+
 extern "C" int sgx_grm_init(const uint8_t *packed, size_t bytes_per_marker, int32_t n_samp,
 	size_t n_markers, int device, sgx_grm **out)
+{
+	return grm_init_impl(packed, bytes_per_marker, n_samp, n_markers, device, out, hipMemcpyHostToDevice);
+}
+
+// same, the packed matrix already resident in this GPU's HBM (it is copied)
+extern "C" int sgx_grm_init_dev(const uint8_t *packed_dev, size_t bytes_per_marker, int32_t n_samp,
+	size_t n_markers, int device, sgx_grm **out)
+{
+	return grm_init_impl(packed_dev, bytes_per_marker, n_samp, n_markers, device, out, hipMemcpyDeviceToDevice);
+}
+
+static int grm_init_impl(const uint8_t *packed, size_t bytes_per_marker, int32_t n_samp,
+	size_t n_markers, int device, sgx_grm **out, hipMemcpyKind kind)
 {
 	if (!packed || !out) return fail(SGX_EINVAL, "sgx_grm_init: NULL argument");
 	*out = nullptr;
@@ -809,7 +825,7 @@ extern "C" int sgx_grm_init(const uint8_t *packed, size_t bytes_per_marker, int3
 	GTRY(hipMemsetAsync(g->G, 0, M * g->bpvN, g->stream));
 	GTRY(hipMemsetAsync(g->Gt, 0, N * g->bpvM, g->stream));
 	GTRY(hipMemcpy2DAsync(g->G, g->bpvN, packed, bytes_per_marker, std::min(bytes_per_marker, g->bpvN), M,
-		hipMemcpyHostToDevice, g->stream));
+		kind, g->stream));
 	for (double **p : {&g->af, &g->inv, &g->l0, &g->xv, &g->gv}) GTRY(hipMalloc((void **)p, M * sizeof(double)));
 	for (double **p : {&g->diag, &g->vb, &g->vout, &g->r, &g->z, &g->p, &g->x, &g->Ap, &g->minv, &g->w})
 		GTRY(hipMalloc((void **)p, N * sizeof(double)));
@@ -908,5 +924,21 @@ extern "C" int sgx_grm_pcg(sgx_grm *g, const double *w, const double *tau, const
 	HIPCHK(hipMemcpyAsync(x_out, g->x, nb, hipMemcpyDeviceToHost, st));
 	HIPCHK(hipStreamSynchronize(st));
 	if (iters_out) *iters_out = iter;
+	return SGX_OK;
+}
+
+// out = GRM b with b, out device vectors of N doubles (asynchronous until sgx_grm_sync)
+extern "C" int sgx_grm_crossprod_dev(sgx_grm *g, const double *b_dev, double *out_dev)
+{
+	if (!g || !b_dev || !out_dev) return fail(SGX_EINVAL, "sgx_grm_crossprod_dev: NULL argument");
+	HIPCHK(hipSetDevice(g->device));
+	return grm_matvec_dev(g, b_dev, out_dev);
+}
+
+extern "C" int sgx_grm_sync(sgx_grm *g)
+{
+	if (!g) return fail(SGX_EINVAL, "sgx_grm_sync: NULL handle");
+	HIPCHK(hipSetDevice(g->device));
+	HIPCHK(hipStreamSynchronize(g->stream));
 	return SGX_OK;
 }
