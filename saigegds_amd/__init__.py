@@ -8,5 +8,6 @@ The compute lives in libsaigehip.so (include/saigehip.h); there is no CPU path.
 """
 from .nullmod import NullModel, ScanModel, init_nullmod, load_modobj  # noqa: F401
 from .assoc import GenotypeSource, seqAssocGLMM_SPA  # noqa: F401
+from .fitnull import FittedNullModel, seqFitNullGLMM_SPA  # noqa: F401
 
 __version__ = "0.1.0"

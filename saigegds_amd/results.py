@@ -97,3 +97,73 @@ def save_result(ans: Dict[str, Any], fn: str, res_compress: str = "LZMA", sample
         raise ValueError("Unknown format of the output file, and it should be RData, RDS or gds.")
     with open(fn, "wb") as f:
         f.write(_compress(raw, res_compress))
+
+
+# ---------------------------------------------------------------------------
+# model file of seqFitNullGLMM_SPA(model.savefn=)  (reference R/saige_main.r:630-643)
+
+
+def _with_attr(payload: bytes, attrs) -> bytes:
+    """Set the has-attribute flag of a serialised vector and append its pairlist."""
+    if not attrs:
+        return payload
+    flags = struct.unpack(">i", payload[:4])[0] | 0x200
+    return _i(flags) + payload[4:] + _pairlist(attrs)
+
+
+def _num(a, names=None) -> bytes:
+    a = np.asarray(a)
+    attrs = []
+    if a.ndim == 2:
+        attrs.append(("dim", _i(13) + _i(2) + _i(a.shape[0]) + _i(a.shape[1])))
+        a = a.T        # column-major
+    if names is not None:
+        attrs.append(("names", _strsxp(list(names))))
+    return _with_attr(_vector(np.ascontiguousarray(a).ravel()), attrs)
+
+
+def _rlist(items, rclass=None, data_frame_rows=None) -> bytes:
+    names = [k for k, _ in items]
+    attrs = [("names", _strsxp(names))]
+    if data_frame_rows is not None:
+        attrs.append(("row.names", _i(13) + _i(2) + _i(NA_INT) + _i(-int(data_frame_rows))))
+    if rclass:
+        attrs.append(("class", _strsxp([rclass])))
+    flags = 19 | 0x200 | (0x100 if rclass else 0)
+    return _i(flags) + _i(len(items)) + b"".join(p for _, p in items) + _pairlist(attrs)
+
+
+def serialize_model(m) -> bytes:
+    """The ``ClassSAIGE_NullModel`` list (man/seqFitNullGLMM_SPA.Rd:75-93)."""
+    vr = m.var_ratio_table
+    nk = _rlist([("y", _num(m.y)), ("mu", _num(m.mu_noK)), ("res", _num(m.res_noK)), ("V", _num(m.V)),
+                 ("X1", _num(m.X1)), ("XV", _num(m.XV)), ("XXVX_inv", _num(m.XXVX_inv))], rclass="SA_NULL")
+    vrl = _rlist([(k, _num(np.asarray(vr[k], dtype=np.float64 if k != "id" else np.int32)))
+                  for k in ("id", "maf", "mac", "var1", "var2", "ratio")],
+                 rclass="data.frame", data_frame_rows=len(vr["ratio"]))
+    items = [
+        ("coefficients", _num(m.coefficients, names=getattr(m, "coef_names", None))),
+        ("tau", _num(m.tau, names=["Sigma_E", "Sigma_G"])),
+        ("linear.predictors", _num(m.linear_predictors)),
+        ("fitted.values", _num(m.fitted_values)),
+        ("residuals", _num(m.residuals)),
+        ("cov", _num(m.cov)),
+        ("converged", _vector(np.array([bool(m.converged)]))),
+        ("obj.noK", nk),
+        ("var.ratio", vrl),
+        ("trait.type", _strsxp([m.trait_type])),
+        ("sample.id", _vector(list(m.sample_id))),
+        ("variant.id", _vector(np.asarray(m.variant_id))),
+    ]
+    return _HEADER + _rlist(items, rclass="ClassSAIGE_NullModel")
+
+
+def save_model(m, fn: str):
+    if re.search(r"\.(rda|RData)$", fn, re.I):
+        raw = b"RDX2\n" + _HEADER + _pairlist([(".glmm", serialize_model(m)[len(_HEADER):])])
+    elif re.search(r"\.rds$", fn, re.I):
+        raw = serialize_model(m)
+    else:
+        raise ValueError("Unknown format of the output file, and it should be RData or RDS.")
+    with open(fn, "wb") as f:
+        f.write(gzip.compress(raw))

@@ -11,6 +11,7 @@ Inputs (data files of the reference's test-suite, inst/unitTests/test_SAIGE.R:79
   inst/unitTests/saige_model_quant.rds  quantitative null model (input of test.saige_pval)
   inst/unitTests/saige_pval.rds         golden result table, binary
   inst/unitTests/saige_pval_quant.rds   golden result table, quantitative
+  inst/extdata/pheno.txt.gz             phenotypes + covariates (input of test.saige_fit_null_model)
 Outputs are data only (decoded arrays); no reference source is copied.
 """
 import os
@@ -29,10 +30,32 @@ REF = os.environ.get("SAIGE_REFERENCE", "/root/reference") + "/inst/"
 
 def save_model(src, dst):
     m = load_modobj(REF + src)
+    r = read_rds(REF + src)          # every field checkEquals() compares (test_SAIGE.R:67-75)
+    vr, nk = r["var.ratio"], r["obj.noK"]
     np.savez_compressed(
         os.path.join(HERE, dst), trait_type=np.array(m.trait_type), tau=m.tau,
         fitted_values=m.fitted_values, sample_id=np.array(m.sample_id), var_ratio=m.var_ratio,
-        y=m.y, V=m.V, X1=m.X1, XV=m.XV, XXVX_inv=m.XXVX_inv)
+        y=m.y, V=m.V, X1=m.X1, XV=m.XV, XXVX_inv=m.XXVX_inv,
+        coefficients=np.asarray(r["coefficients"], dtype=np.float64),
+        linear_predictors=np.asarray(r["linear.predictors"], dtype=np.float64),
+        residuals=np.asarray(r["residuals"], dtype=np.float64),
+        cov=np.asarray(r["cov"], dtype=np.float64), converged=np.array(bool(np.asarray(r["converged"]).ravel()[0])),
+        variant_id=np.asarray(r["variant.id"]),
+        noK_mu=np.asarray(nk["mu"], dtype=np.float64), noK_res=np.asarray(nk["res"], dtype=np.float64),
+        **{"vr_" + k: np.asarray(vr[k], dtype=np.float64) for k in ("id", "maf", "mac", "var1", "var2", "ratio")})
+
+
+def save_pheno():
+    import gzip
+    with gzip.open(REF + "extdata/pheno.txt.gz", "rt") as f:
+        hdr = f.readline().split()
+        rows = [ln.split() for ln in f if ln.strip()]
+    out = {}
+    for i, h in enumerate(hdr):
+        col = [r[i] for r in rows]
+        out[h.replace(".", "_")] = np.array(col) if h == "sample.id" else np.array(
+            [np.nan if c == "NA" else float(c) for c in col])
+    np.savez_compressed(os.path.join(HERE, "pheno.npz"), **out)
 
 
 def save_table(src, dst, cols):
@@ -63,6 +86,7 @@ def main():
 
     save_model("unitTests/saige_model.rds", "saige_model.npz")
     save_model("unitTests/saige_model_quant.rds", "saige_model_quant.npz")
+    save_pheno()
     save_table("unitTests/saige_pval.rds", "saige_pval.npz",
                ["id", "chr", "pos", "rs.id", "ref", "alt", "AF.alt", "mac", "num", "beta", "SE",
                 "pval", "p.norm", "converged"])
