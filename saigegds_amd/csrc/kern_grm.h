@@ -150,7 +150,7 @@ limbs_kernel(const double *__restrict__ x, size_t n, size_t n_pad, int col0,
 			const double v = x[i];
 			q = isfinite(v) ? __double2ll_rn(ldexp(v, e)) : 0;
 		}
-		uint8_t *base = Fl + ((i >> 4) * GRM_NCOL + col0) * 16 + (i & 15);
+		uint8_t *base = Fl + ((i >> 4) * GRM_NCOL + col0) * 16 + mf_pos((int)(i & 15));
 		long long rem = q;
 #pragma unroll
 		for (int l = 0; l < MF_NLIMB; l++) {

@@ -53,17 +53,22 @@ struct MfTab {
 	long long ftot_lo[MF_MAXP + 1];
 };
 
-// 16 two-bit codes -> 16 bytes: value plane (0..3) and twice their bit 1 (0/2)
+// Sample order inside a group of 16.  One dword of the packed row holds 16 codes,
+// code s in bits 2s..2s+1.  The A fragment takes them as 4 dwords of 4 bytes; with
+//     val[t] = (w >> 2t) & 0x03030303      (byte j of val[t] = code of sample 4j + t)
+// the unpack is two VALU operations per dword, and the B tiles simply store the 16
+// samples of a group in that same order: sample s at byte mf_pos(s) = 4 (s & 3) + (s >> 2).
+__host__ __device__ __forceinline__ int mf_pos(int s) { return ((s & 3) << 2) | (s >> 2); }
+
+// value plane (codes 0..3) and twice their bit 1 (0/2)
 __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 {
+	val[0] = (int)(w & 0x03030303u);
+	val[1] = (int)((w >> 2) & 0x03030303u);
+	val[2] = (int)((w >> 4) & 0x03030303u);
+	val[3] = (int)((w >> 6) & 0x03030303u);
 #pragma unroll
-	for (int k = 0; k < 4; k++) {
-		const uint32_t t = (w >> (8 * k)) & 0xFFu;
-		const uint32_t y = (t | (t << 12)) & 0x000F000Fu;
-		const uint32_t z = (y | (y << 6)) & 0x03030303u;
-		val[k] = (int)z;
-		b1[k] = (int)(z & 0x02020202u);   // bit 1 kept in place: the plane is 2*[code>=2]
-	}
+	for (int k = 0; k < 4; k++) b1[k] = (int)((uint32_t)val[k] & 0x02020202u);   // the plane is 2*[code>=2]
 }
 
 // grid = (variant tiles of MF_VPB, sample splits); block = 64 * MF_WAVES.
@@ -87,8 +92,17 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 
 	const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
 	const int r = lane & 15, kg = lane >> 4;
-	const int vbase = blockIdx.x * MF_VPB + wid * MF_VPW;
-	const int t0 = blockIdx.y * tiles_per_split;
+	// Workgroups are handed to the 8 XCDs round-robin in dispatch order, so those with the same
+	// (linear id % 8) share an L2.  Give each such group whole sample splits: its resident
+	// workgroups then stream the same B tiles, which stay in that L2, while every packed row
+	// is still read once.  (A placement guess only: correctness does not depend on it.)
+	unsigned vt_idx = blockIdx.x, split = blockIdx.y;
+	{
+		const unsigned VT = gridDim.x, L = blockIdx.y * VT + blockIdx.x, full = gridDim.y & ~7u;
+		if (L < full * VT) { const unsigned q = L >> 3; split = 8 * (q / VT) + (L & 7); vt_idx = q % VT; }
+	}
+	const int vbase = vt_idx * MF_VPB + wid * MF_VPW;
+	const int t0 = split * tiles_per_split;
 	const int t1 = min(tb.ntile, t0 + tiles_per_split);
 
 	v4i acc[MF_NAF][NBF], accm[MF_NAF][NBFV];
@@ -150,11 +164,12 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 					acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(val, bfrag[b], acc[f][b], 0, 0, 0);
 				if (HAS_B1) acc[f][NBF - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, bfrag[NBF - 1], acc[f][NBF - 1], 0, 0, 0);
 				// samples beyond N have all-zero limbs, so stray codes there add nothing
-				if (__ballot((w & (w >> 1) & LO_MASK) != 0)) {
+				const uint32_t m3 = w & (w >> 1) & LO_MASK;
+				if (__ballot(m3 != 0)) {
 					saw_missing = true;
 					v4i ms;
 #pragma unroll
-					for (int k = 0; k < 4; k++) ms[k] = (int)((uint32_t)val[k] & ((uint32_t)val[k] >> 1) & 0x01010101u);
+					for (int k = 0; k < 4; k++) ms[k] = (int)((m3 >> (2 * k)) & 0x01010101u);
 #pragma unroll
 					for (int b = 0; b < NBFV; b++)
 						accm[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(ms, bfrag[b], accm[f][b], 0, 0, 0);

@@ -217,7 +217,7 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 			for (int i = 0; i < N; i++) {
 				long long q = std::llrint(std::ldexp(Fc(i), tb.escale[c]));
 				tot += q;
-				int8_t *base = &Fl[((size_t)(i / 16) * tb.ncol) * 16 + (i % 16)];
+				int8_t *base = &Fl[((size_t)(i / 16) * tb.ncol) * 16 + mf_pos(i % 16)];
 				long long rem = q;
 				for (int l = 0; l < MF_NLIMB; l++) {
 					long long d = (l < MF_NLIMB - 1) ? (((rem + 128) & 255) - 128) : rem;
@@ -232,8 +232,8 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 			tb.ftot_hi[c] = (long long)hi; tb.ftot_lo[c] = (long long)lo;
 		}
 		for (int i = 0; i < N; i++) {
-			Fl[((size_t)(i / 16) * tb.ncol + tb.col_ones) * 16 + (i % 16)] = 1;
-			Fl[((size_t)(i / 16) * tb.ncol + tb.col_b1 + MF_NLIMB) * 16 + (i % 16)] = 1;
+			Fl[((size_t)(i / 16) * tb.ncol + tb.col_ones) * 16 + mf_pos(i % 16)] = 1;
+			Fl[((size_t)(i / 16) * tb.ncol + tb.col_b1 + MF_NLIMB) * 16 + mf_pos(i % 16)] = 1;
 		}
 		h->mf_ok = true;
 	}
@@ -339,6 +339,19 @@ static int ensure_recs(sgx_handle *h, size_t n)
 
 #define FOR_EACH_K(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 
+// Sample splits of the MFMA kernels: a few rounds of 2 workgroups per CU, and a multiple of
+// 8 splits when there are that many, so that each XCD works on whole splits (kern_score_mfma.h)
+static dim3 mf_grid(int n_cu, size_t rows, int ntile, int *tps)
+{
+	const int vt = (int)((rows + MF_VPB - 1) / MF_VPB);
+	int sk = std::max(1, (n_cu * 2 * 4 + vt / 2) / vt);
+	if (sk >= 6) sk = (sk + 7) & ~7;
+	sk = std::min(sk, ntile);
+	*tps = (ntile + sk - 1) / sk;
+	sk = (ntile + *tps - 1) / *tps;
+	return dim3((unsigned)vt, (unsigned)sk);
+}
+
 template <int INPUT>
 static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t M,
 	double *out8, uint8_t *valid)
@@ -354,13 +367,8 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		const MfTab &tb = h->mf;
 		const int P = md.P;
 		HIPCHK(hipMemsetAsync(h->mf_acc, 0, M * (size_t)tb.nacc * sizeof(int), st));
-		const int vt = (int)((M + MF_VPB - 1) / MF_VPB);
-		// split the samples so that the grid is a few rounds of 2 workgroups per CU
-		int sk = std::max(1, (h->n_cu * 2 * 4 + vt / 2) / vt);
-		sk = std::min(sk, tb.ntile);
-		const int tps = (tb.ntile + sk - 1) / sk;
-		sk = (tb.ntile + tps - 1) / tps;
-		const dim3 mgrid((unsigned)vt, (unsigned)sk);
+		int tps = 0;
+		const dim3 mgrid = mf_grid(h->n_cu, M, tb.ntile, &tps);
 		const size_t lds = (size_t)2 * 16 * tb.ncol * 16;
 #define MFCASE(NB, PP)                                                                        \
 	hipLaunchKernelGGL((score_mfma_kernel<NB, true>), mgrid, dim3(WAVE * MF_WAVES), lds, st,    \
@@ -718,12 +726,7 @@ static int grm_sum(sgx_grm *g, const double *a, const double *b, size_t n, doubl
 
 static dim3 grm_mfma_grid(const sgx_grm *g, size_t rows, int ntile, int *tps)
 {
-	const int vt = (int)((rows + MF_VPB - 1) / MF_VPB);
-	int sk = std::max(1, (g->n_cu * 2 * 4 + vt / 2) / vt);
-	sk = std::min(sk, ntile);
-	*tps = (ntile + sk - 1) / sk;
-	sk = (ntile + *tps - 1) / *tps;
-	return dim3((unsigned)vt, (unsigned)sk);
+	return mf_grid(g->n_cu, rows, ntile, tps);
 }
 
 // out = G'(G b)/M, device vectors (get_crossprod_b_grm, saige_fitnull.cpp:435-536)
