@@ -34,7 +34,9 @@
 typedef int v4i __attribute__((ext_vector_type(4)));
 
 #define MF_NAF 4             /* A fragments (16 variants each) per wave      */
+#ifndef MF_WAVES
 #define MF_WAVES 4           /* waves per workgroup -> 256 variants          */
+#endif
 #define MF_VPW (16 * MF_NAF) /* variants per wave                            */
 #define MF_VPB (MF_VPW * MF_WAVES)
 #define MF_NLIMB 7
@@ -78,8 +80,14 @@ __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 // a missing code, which a wave decides with one ballot.
 // HAS_B1 = false drops the bit-1 plane and its fragment (the implicit-GRM products
 // of kern_grm.h only need the code plane and the missing plane).
-template <int NBFV, bool HAS_B1>
-__global__ void __launch_bounds__(WAVE * MF_WAVES, 2)
+// ABL: switches of the timing tool tools/mfma_ablate.hip (wrong results; the product uses 0):
+//   1 no missing plane, 2 no bit-1 MFMA, 4 no unpack, 16 no A loads, 32 no B DMA,
+//   64 no arithmetic at all (loads, DMA, LDS reads and barriers only),
+//   256 rows of a fragment stored as one contiguous KiB per tile (layout experiment),
+//   512 A rows fetched by LDS-DMA instead of into registers (values unused),
+//   1024 s_memtime stamps per tile, 2048 all loads and DMA of a tile issued in one burst at its start
+template <int NBFV, bool HAS_B1, int ABL = 0>
+__global__ void __launch_bounds__(WAVE * MF_WAVES, 8 / MF_WAVES)
 score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab tb,
 	int tiles_per_split, int *__restrict__ accbuf)
 {
@@ -119,11 +127,14 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 	// tile (sgx_row_stride), rows past M are clamped (their sums are never stored)
 	const uint8_t *rowp[MF_NAF];
 #pragma unroll
-	for (int f = 0; f < MF_NAF; f++)
+	for (int f = 0; f < MF_NAF; f++) {
 		rowp[f] = packed + (size_t)min(vbase + 16 * f + r, M - 1) * bpv + (size_t)t0 * 64 + 16 * kg;
+		if (ABL & 256) rowp[f] = packed + ((size_t)(min(vbase + 16 * f, M - 16) / 16) * tb.ntile + t0) * 1024 + lane * 16;
+	}
 
 	// B tile t -> LDS buffer (t & 1) by LDS-DMA: 1 KiB per wave-instruction, lane-linear
 	auto issue_B = [&](int t) {
+		if (ABL & 32) return;
 		const uint8_t *src = tb.Fl + (size_t)t * TILE_BYTES;
 		uint8_t *dst = ldsB + (size_t)(t & 1) * TILE_BYTES;
 #pragma unroll
@@ -136,16 +147,50 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 	auto load_A = [&](uint4 (&a)[MF_NAF]) {
 #pragma unroll
 		for (int f = 0; f < MF_NAF; f++) {
+			if (ABL & 512) {   // experiment: the same bytes by LDS-DMA (into scratch LDS), values unused
+				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rowp[f],
+					(__attribute__((address_space(3))) void *)(smem + 2 * TILE_BYTES + (wid * MF_NAF + f) * 1024), 16, 0, 0);
+				rowp[f] += (ABL & 256) ? 1024 : 64;
+				a[f] = make_uint4(t0 + f, lane, wid, 0x01010101u);
+				continue;
+			}
+			if (ABL & 16) { a[f] = make_uint4(t0 + f, lane, wid, 0x01010101u); continue; }
 			a[f] = *reinterpret_cast<const uint4 *>(rowp[f]);
-			rowp[f] += 64;
+			rowp[f] += (ABL & 256) ? 1024 : 64;
 		}
 	};
 
 	uint4 acur[MF_NAF], anxt[MF_NAF];
 	if (t0 < t1) { load_A(acur); issue_B(t0); }
+	// ABL & 1024: s_memtime stamps -> cycles spent waiting at the tile barrier / issuing loads / computing
+	unsigned long long st_wait = 0, st_issue = 0, st_comp = 0, st_prev = 0;
+#define MF_STAMP(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory")
+	if (ABL & 1024) MF_STAMP(st_prev);
 	for (int t = t0; t < t1; t++) {
 		__syncthreads();   // tile t landed (each wave drained its own DMA), tile t-1 fully consumed
-		if (t + 1 < t1) { load_A(anxt); issue_B(t + 1); }
+		unsigned long long sa = 0, sb = 0;
+		if (ABL & 1024) { __builtin_amdgcn_sched_barrier(0); MF_STAMP(sa); __builtin_amdgcn_sched_barrier(0); st_wait += sa - st_prev; }
+		constexpr bool SPREAD = !(ABL & (2048 | 16 | 512));   // one VMEM instruction per MFMA group (else: all at the tile start)
+		const bool more = t + 1 < t1;
+		if (!SPREAD && more) { load_A(anxt); issue_B(t + 1); }
+		auto vmem_slot = [&](int idx) {
+			if (!SPREAD || !more) return;
+			if (idx < MF_NAF) {
+				anxt[idx] = *reinterpret_cast<const uint4 *>(rowp[idx]);
+				rowp[idx] += (ABL & 256) ? 1024 : 64;
+			} else {
+				const int k = wid + (idx - MF_NAF) * MF_WAVES;
+				if (!(ABL & 32) && k < TILE_BYTES / 1024) {
+					const uint8_t *src = tb.Fl + (size_t)(t + 1) * TILE_BYTES;
+					uint8_t *dst = ldsB + (size_t)((t + 1) & 1) * TILE_BYTES;
+					__builtin_amdgcn_global_load_lds(
+						(const __attribute__((address_space(1))) void *)(src + (size_t)k * 1024 + lane * 16),
+						(__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
+				}
+			}
+			__builtin_amdgcn_sched_barrier(0);
+		};
+		if (ABL & 1024) { __builtin_amdgcn_sched_barrier(0); MF_STAMP(sb); __builtin_amdgcn_sched_barrier(0); st_issue += sb - sa; }
 		const uint8_t *bt = ldsB + (size_t)(t & 1) * TILE_BYTES;
 #pragma unroll
 		for (int u = 0; u < 4; u++) {
@@ -157,15 +202,18 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 #pragma unroll
 			for (int f = 0; f < MF_NAF; f++) {
 				const uint32_t w = (u == 0) ? acur[f].x : (u == 1) ? acur[f].y : (u == 2) ? acur[f].z : acur[f].w;
+				vmem_slot(u * MF_NAF + f);
+				if (ABL & 64) { acc[f][0][0] ^= (int)w ^ bfrag[0][0]; continue; }
 				v4i val, b1;
-				mf_unpack(w, val, b1);
+				if (ABL & 4) { val = (v4i){(int)w, (int)w, (int)w, (int)w}; b1 = val; }
+				else mf_unpack(w, val, b1);
 #pragma unroll
 				for (int b = 0; b < NBFV; b++)
 					acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(val, bfrag[b], acc[f][b], 0, 0, 0);
-				if (HAS_B1) acc[f][NBF - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, bfrag[NBF - 1], acc[f][NBF - 1], 0, 0, 0);
+				if (HAS_B1 && !(ABL & 2)) acc[f][NBF - 1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1, bfrag[NBF - 1], acc[f][NBF - 1], 0, 0, 0);
 				// samples beyond N have all-zero limbs, so stray codes there add nothing
 				const uint32_t m3 = w & (w >> 1) & LO_MASK;
-				if (__ballot(m3 != 0)) {
+				if (!(ABL & 1) && __ballot(m3 != 0)) {
 					saw_missing = true;
 					v4i ms;
 #pragma unroll
@@ -176,8 +224,14 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 				}
 			}
 		}
+		if (ABL & 1024) { __builtin_amdgcn_sched_barrier(0); MF_STAMP(st_prev); __builtin_amdgcn_sched_barrier(0); st_comp += st_prev - sb; }
 #pragma unroll
 		for (int f = 0; f < MF_NAF; f++) acur[f] = anxt[f];
+	}
+	if ((ABL & 1024) && lane == 0) {
+		unsigned long long *dbg = reinterpret_cast<unsigned long long *>(accbuf + (size_t)M * NACC) +
+			((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * MF_WAVES + wid) * 4;
+		dbg[0] = st_wait; dbg[1] = st_issue; dbg[2] = st_comp; dbg[3] = (unsigned long long)(t1 - t0);
 	}
 
 	// ---- results: integer atomics (exact, order-independent)
@@ -200,6 +254,7 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 	}
 }
 
+#ifndef MF_KERNEL_ONLY   /* tools/mfma_ablate.hip takes the contraction kernel alone */
 // value = hi * 2^32 + lo, both parts small enough to be exact in a double
 struct HiLo { long long hi, lo; };
 __device__ __forceinline__ double hl_to_double(HiLo x) { return (double)x.hi * 4294967296.0 + (double)x.lo; }
@@ -280,6 +335,8 @@ score_mfma_epilogue(int M, DevModel md, MfTab tb, const int *__restrict__ accbuf
 	}
 	atomicAdd(&counters[1], 1);
 }
+
+#endif /* MF_KERNEL_ONLY */
 
 // Lane-map self-test of v_mfma_i32_16x16x64_i8 with asymmetric integer data:
 //   A[row l&15][k = 16(l>>4)+j], B[k = 16(l>>4)+j][col l&15], D[(l>>4)*4+reg][l&15]
