@@ -40,19 +40,30 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #define MF_VPW (16 * MF_NAF) /* variants per wave                            */
 #define MF_VPB (MF_VPW * MF_WAVES)
 #define MF_NLIMB 7
-#define MF_MAXP 10           /* 2K+2 supported by the MFMA path (K <= 4)     */
+#define MF_GCOLS 9           /* value columns per column group: 9 x 7 limbs + 1 = 64 = 4 B fragments */
+#define MF_MAXP (2 * SGX_MAX_COEFF + 3)   /* value columns: c' (K), e (K), s, w, mu                 */
+#define MF_MAXG ((MF_MAXP + MF_GCOLS - 1) / MF_GCOLS)
 
+// what the contraction kernel needs of one column group
 struct MfTab {
-	const uint8_t *Fl;         // [ngrp_pad][ncol][16] int8 limb digits, sample-fastest
-	int ncol;                  // 16 * (nbfv + 1): columns of one B tile
-	int nbfv;                  // B fragments used with the value plane
-	int nacc;                  // ints per variant in the accumulator buffer = ncol + 16 * nbfv
-	int col_ones;              // column of the constant 1
-	int col_b1;                // first column of the mu2 limbs in the bit-1 fragment
+	const uint8_t *Fl;         // [ngrp_pad][NCOL][16] int8 limb digits, sample order mf_pos()
 	int ntile;                 // number of 256-sample tiles = ngrp_pad / 16
-	int escale[MF_MAXP + 1];   // F = q * 2^-escale; column P is mu (for the SPA stage's m1)
-	long long ftot_hi[MF_MAXP + 1]; // sum_i q[i,c] = hi * 2^32 + lo
-	long long ftot_lo[MF_MAXP + 1];
+};
+
+// Column groups.  With K covariates the score stage needs 2K + 3 sums of 7 limbs each; a
+// workgroup's accumulators hold 4 B fragments (64 limb columns), so the value columns are cut
+// into groups of MF_GCOLS and the contraction kernel runs once per group over the same packed
+// rows (K <= 3: one group).  Group 0 also carries the constant-1 column and the bit-1 fragment.
+// Accumulator row of a variant = the groups' rows one after the other: goff[g] ints in, group g
+// has gncol[g] ints of value (+ bit-1) sums followed by 16 * nbfv[g] ints of missing-plane sums.
+struct MfEpi {
+	int ngroups, acc_stride;
+	int goff[MF_MAXG], gncol[MF_MAXG];
+	int col_ones;              // group 0: column of the constant 1
+	int col_b1;                // group 0: first column of the mu2 limbs in the bit-1 fragment
+	int escale[MF_MAXP];       // F = q * 2^-escale
+	long long ftot_hi[MF_MAXP];// sum_i q[i,c] = hi * 2^32 + lo
+	long long ftot_lo[MF_MAXP];
 };
 
 // Sample order inside a group of 16.  One dword of the packed row holds 16 codes,
@@ -89,11 +100,10 @@ __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 template <int NBFV, bool HAS_B1, int ABL = 0>
 __global__ void __launch_bounds__(WAVE * MF_WAVES, 8 / MF_WAVES)
 score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab tb,
-	int tiles_per_split, int *__restrict__ accbuf)
+	int tiles_per_split, int *__restrict__ accbuf, int acc_stride)
 {
 	constexpr int NBF = NBFV + (HAS_B1 ? 1 : 0);
 	constexpr int NCOL = 16 * NBF;
-	constexpr int NACC = NCOL + 16 * NBFV;
 	constexpr int TILE_BYTES = 16 * NCOL * 16;
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // 2 x TILE_BYTES, nothing else
 	uint8_t *ldsB = smem;
@@ -229,7 +239,7 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 		for (int f = 0; f < MF_NAF; f++) acur[f] = anxt[f];
 	}
 	if ((ABL & 1024) && lane == 0) {
-		unsigned long long *dbg = reinterpret_cast<unsigned long long *>(accbuf + (size_t)M * NACC) +
+		unsigned long long *dbg = reinterpret_cast<unsigned long long *>(accbuf + (size_t)M * acc_stride) +
 			((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * MF_WAVES + wid) * 4;
 		dbg[0] = st_wait; dbg[1] = st_issue; dbg[2] = st_comp; dbg[3] = (unsigned long long)(t1 - t0);
 	}
@@ -241,7 +251,7 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 		for (int reg = 0; reg < 4; reg++) {
 			const int v = vbase + 16 * f + kg * 4 + reg;
 			if (v < M) {
-				int *dst = accbuf + (size_t)v * NACC;
+				int *dst = accbuf + (size_t)v * acc_stride;
 #pragma unroll
 				for (int b = 0; b < NBF; b++) atomicAdd(&dst[b * 16 + r], acc[f][b][reg]);
 				if (saw_missing) {
@@ -273,20 +283,21 @@ __device__ __forceinline__ HiLo mf_limbs(const int *a)
 }
 
 // one thread per variant: integer recombination, then the common epilogue
-template <int P>
+template <int K>
 __global__ void __launch_bounds__(256)
-score_mfma_epilogue(int M, DevModel md, MfTab tb, const int *__restrict__ accbuf,
+score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf,
 	SpaRec *__restrict__ recs, int *__restrict__ counters, double *__restrict__ out8,
 	uint8_t *__restrict__ valid)
 {
+	constexpr int P = 2 * K + 2, CW = P - 1;     // score columns; column CW carries G^2, column P is mu
 	const int j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= M) return;
-	const int *a = accbuf + (size_t)j * tb.nacc;     // value plane + bit-1 fragment
-	const int *am = a + tb.ncol;                      // value columns over missing samples
+	const int *a0 = accbuf + (size_t)j * ep.acc_stride;   // group 0: value plane + bit-1 fragment
+	const int *am0 = a0 + ep.gncol[0];                     // group 0: value columns over missing samples
 	const int N = md.N;
-	const int n3 = am[tb.col_ones];
-	const long long AC = (long long)a[tb.col_ones] - 3ll * n3;
-	const int n2 = a[tb.col_b1 + MF_NLIMB] / 2 - n3;       // bit-1 plane (0/2) against the ones column
+	const int n3 = am0[ep.col_ones];
+	const long long AC = (long long)a0[ep.col_ones] - 3ll * n3;
+	const int n2 = a0[ep.col_b1 + MF_NLIMB] / 2 - n3;      // bit-1 plane (0/2) against the ones column
 	const int n1 = (int)(AC - 2ll * n2);
 	const VarHead h = make_head(md, (double)AC, N - n3);
 	double *o = out8 + (size_t)j * 8;
@@ -296,18 +307,20 @@ score_mfma_epilogue(int M, DevModel md, MfTab tb, const int *__restrict__ accbuf
 	HiLo Wm = hl(0, 0), T3m = hl(0, 0);
 #pragma unroll
 	for (int c = 0; c < P + 1; c++) {
-		const HiLo V = mf_limbs(a + c * MF_NLIMB);
-		const HiLo T3 = mf_limbs(am + c * MF_NLIMB);
+		const int g = c / MF_GCOLS, cc = (c - g * MF_GCOLS) * MF_NLIMB;
+		const int *a = a0 + ep.goff[g];
+		const HiLo V = mf_limbs(a + cc);
+		const HiLo T3 = mf_limbs(a + ep.gncol[g] + cc);
 		const HiLo W = hl_axpy(-3, T3, V);
 		const double t3d = hl_to_double(T3);
 		double s;
 		if (!h.minus) s = hl_to_double(W) + imp * t3d;
-		else s = hl_to_double(hl(2 * tb.ftot_hi[c] - W.hi, 2 * tb.ftot_lo[c] - W.lo)) - imp * t3d;
-		acc[c] = ldexp(s, -tb.escale[c]);
-		if (c == P - 1) { Wm = W; T3m = T3; }
+		else s = hl_to_double(hl(2 * ep.ftot_hi[c] - W.hi, 2 * ep.ftot_lo[c] - W.lo)) - imp * t3d;
+		acc[c] = ldexp(s, -ep.escale[c]);
+		if (c == CW) { Wm = W; T3m = T3; }
 	}
-	{   // last column carries G^2
-		const HiLo B2 = mf_limbs(a + tb.col_b1);          // = 2 (T2 + T3), the plane holds 0/2
+	{
+		const HiLo B2 = mf_limbs(a0 + ep.col_b1);         // = 2 (T2 + T3), the plane holds 0/2
 		const HiLo H2 = hl(B2.hi / 2 - T3m.hi, B2.lo / 2 - T3m.lo);   // every limb sum of that plane is even
 		const double t3d = hl_to_double(T3m);
 		double w;
@@ -316,10 +329,10 @@ score_mfma_epilogue(int M, DevModel md, MfTab tb, const int *__restrict__ accbuf
 		} else {
 			const HiLo S1 = hl_axpy(-2, H2, Wm);
 			// 4 (Ftot - S1 - H2 - T3) + S1
-			const HiLo R = hl(tb.ftot_hi[P - 1] - S1.hi - H2.hi - T3m.hi, tb.ftot_lo[P - 1] - S1.lo - H2.lo - T3m.lo);
+			const HiLo R = hl(ep.ftot_hi[CW] - S1.hi - H2.hi - T3m.hi, ep.ftot_lo[CW] - S1.lo - H2.lo - T3m.lo);
 			w = hl_to_double(hl_axpy(4, R, S1)) + (2 - imp) * (2 - imp) * t3d;
 		}
-		acc[P - 1] = ldexp(w, -tb.escale[P - 1]);
+		acc[CW] = ldexp(w, -ep.escale[CW]);
 	}
 	double cbuf[KMAX], pn, Ssc, v2sc;
 	valid[j] = 1;

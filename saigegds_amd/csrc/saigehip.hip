@@ -89,7 +89,9 @@ struct sgx_handle {
 	bool force_dense = false;         // test hook: every SPA variant takes the exact dense pass
 	// exact-integer MFMA score path (kern_score_mfma.h)
 	bool mf_ok = false;
-	MfTab mf{};
+	MfTab mf[MF_MAXG]{};              // one limb table per column group
+	int mf_nbfv[MF_MAXG]{};
+	MfEpi mfe{};
 	uint8_t *dFl = nullptr;
 	int *mf_acc = nullptr;
 	int n_cu = 256;
@@ -191,49 +193,66 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		f[2 * K] = m->y_mu[i];
 		f[2 * K + 1] = w;
 	}
-	// fixed-point limb tables for the MFMA score path (binary and quantitative alike)
+	// fixed-point limb tables for the MFMA score path (binary and quantitative alike), one per
+	// column group (kern_score_mfma.h)
 	std::vector<int8_t> Fl;
-	if (P <= MF_MAXP && (double)N * 384.0 < 2147483647.0) {
-		MfTab &tb = h->mf;
+	std::vector<size_t> fl_off;
+	if ((double)N * 384.0 < 2147483647.0) {
+		MfEpi &ep = h->mfe;
 		const int PE = P + 1;                       // score columns + mu
-		const int ncolv = MF_NLIMB * PE + 1;
-		tb.nbfv = (ncolv + 15) / 16;
-		tb.ncol = 16 * (tb.nbfv + 1);
-		tb.nacc = tb.ncol + 16 * tb.nbfv;
-		tb.col_ones = MF_NLIMB * PE;
-		tb.col_b1 = 16 * tb.nbfv;
+		const int CW = P - 1;                       // the column that carries G^2 (w)
 		const int ngrp = (N + 15) / 16;
-		tb.ntile = (ngrp + 15) / 16;
-		const size_t ngrp_pad = (size_t)tb.ntile * 16;
-		Fl.assign(ngrp_pad * tb.ncol * 16, 0);
+		const int ntile = (ngrp + 15) / 16;
+		const size_t ngrp_pad = (size_t)ntile * 16;
+		ep.ngroups = (PE + MF_GCOLS - 1) / MF_GCOLS;
+		int off = 0;
+		size_t bytes = 0;
+		for (int g = 0; g < ep.ngroups; g++) {
+			const int cols = std::min(MF_GCOLS, PE - g * MF_GCOLS);
+			const int nb = (MF_NLIMB * cols + (g == 0 ? 1 : 0) + 15) / 16;
+			h->mf_nbfv[g] = nb;
+			ep.gncol[g] = 16 * (nb + (g == 0 ? 1 : 0));
+			ep.goff[g] = off;
+			off += ep.gncol[g] + 16 * nb;
+			fl_off.push_back(bytes);
+			bytes += ngrp_pad * ep.gncol[g] * 16;
+			h->mf[g].ntile = ntile;
+		}
+		ep.acc_stride = off;
+		ep.col_ones = MF_NLIMB * std::min(PE, MF_GCOLS);
+		ep.col_b1 = 16 * h->mf_nbfv[0];
+		Fl.assign(bytes, 0);
+		auto at = [&](int g, int i, int col) -> int8_t & {
+			return Fl[fl_off[g] + ((size_t)(i / 16) * ep.gncol[g] + col) * 16 + mf_pos(i % 16)];
+		};
 		for (int c = 0; c < PE; c++) {
+			const int g = c / MF_GCOLS, cc = (c - g * MF_GCOLS) * MF_NLIMB;
 			auto Fc = [&](int i) { return c < P ? F[(size_t)i * P + c] : m->mu[i]; };
 			double mx = 0;
 			for (int i = 0; i < N; i++) mx = std::max(mx, std::fabs(Fc(i)));
 			int ex = 0;
 			if (mx > 0) (void)std::frexp(mx, &ex);
-			tb.escale[c] = 54 - ex;
+			ep.escale[c] = 54 - ex;
 			__int128 tot = 0;
 			for (int i = 0; i < N; i++) {
-				long long q = std::llrint(std::ldexp(Fc(i), tb.escale[c]));
+				long long q = std::llrint(std::ldexp(Fc(i), ep.escale[c]));
 				tot += q;
-				int8_t *base = &Fl[((size_t)(i / 16) * tb.ncol) * 16 + mf_pos(i % 16)];
 				long long rem = q;
 				for (int l = 0; l < MF_NLIMB; l++) {
 					long long d = (l < MF_NLIMB - 1) ? (((rem + 128) & 255) - 128) : rem;
 					rem = (rem - d) >> 8;
-					base[(size_t)(c * MF_NLIMB + l) * 16] = (int8_t)d;
-					if (c == P - 1) base[(size_t)(tb.col_b1 + l) * 16] = (int8_t)d;
+					at(g, i, cc + l) = (int8_t)d;
+					if (c == CW) at(0, i, ep.col_b1 + l) = (int8_t)d;
 				}
 			}
 			const __int128 two32 = ((__int128)1) << 32;
 			__int128 hi = tot / two32, lo = tot - hi * two32;
 			if (lo < 0) { lo += two32; hi -= 1; }
-			tb.ftot_hi[c] = (long long)hi; tb.ftot_lo[c] = (long long)lo;
+			ep.ftot_hi[c] = (long long)hi; ep.ftot_lo[c] = (long long)lo;
 		}
 		for (int i = 0; i < N; i++) {
-			Fl[((size_t)(i / 16) * tb.ncol + tb.col_ones) * 16 + mf_pos(i % 16)] = 1;
-			Fl[((size_t)(i / 16) * tb.ncol + tb.col_b1 + MF_NLIMB) * 16 + mf_pos(i % 16)] = 1;
+			at(0, i, ep.col_ones) = 1;
+			at(0, i, ep.col_b1 + MF_NLIMB) = 1;
 		}
 		h->mf_ok = true;
 	}
@@ -253,7 +272,7 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 	if (h->mf_ok) {
 		std::vector<uint8_t> Flu(Fl.begin(), Fl.end());
 		TRY(dev_upload(&h->dFl, Flu));
-		h->mf.Fl = h->dFl;
+		for (int g = 0; g < h->mfe.ngroups; g++) h->mf[g].Fl = h->dFl + fl_off[g];
 	}
 	md.F = h->dF; md.X = h->dX; md.y = h->dy; md.mu = h->dmu; md.mu2 = h->dmu2; md.XM = h->dXM;
 	hipError_t e;
@@ -329,7 +348,7 @@ static int ensure_recs(sgx_handle *h, size_t n)
 	if (h->mf_ok) {
 		if (h->mf_acc) HIPCHK(hipFree(h->mf_acc));
 		h->mf_acc = nullptr;
-		HIPCHK(hipMalloc((void **)&h->mf_acc, n * (size_t)h->mf.nacc * sizeof(int)));
+		HIPCHK(hipMalloc((void **)&h->mf_acc, n * (size_t)h->mfe.acc_stride * sizeof(int)));
 	}
 	h->recs_cap = n;
 	return SGX_OK;
@@ -364,25 +383,34 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	const bool use_mf = (INPUT == IN_2BIT) && h->mf_ok && !h->force_v1;
 	if (use_mf) {
-		const MfTab &tb = h->mf;
-		const int P = md.P;
-		HIPCHK(hipMemsetAsync(h->mf_acc, 0, M * (size_t)tb.nacc * sizeof(int), st));
+		const MfEpi &ep = h->mfe;
+		HIPCHK(hipMemsetAsync(h->mf_acc, 0, M * (size_t)ep.acc_stride * sizeof(int), st));
 		int tps = 0;
-		const dim3 mgrid = mf_grid(h->n_cu, M, tb.ntile, &tps);
-		const size_t lds = (size_t)2 * 16 * tb.ncol * 16;
-#define MFCASE(NB, PP)                                                                        \
-	hipLaunchKernelGGL((score_mfma_kernel<NB, true>), mgrid, dim3(WAVE * MF_WAVES), lds, st,    \
-		(const uint8_t *)rows, row_bytes, (int)M, tb, tps, h->mf_acc);                         \
-	hipLaunchKernelGGL((score_mfma_epilogue<PP>), dim3((unsigned)((M + 255) / 256)), dim3(256), \
-		0, st, (int)M, md, tb, h->mf_acc, h->recs, h->counters, out8, valid);
-		switch (P) {
-		case 4: MFCASE(3, 4) break;
-		case 6: MFCASE(4, 6) break;
-		case 8: MFCASE(4, 8) break;
-		case 10: MFCASE(5, 10) break;
-		default: return fail(SGX_EINVAL, "MFMA score path: unsupported P=%d", P);
+		const dim3 mgrid = mf_grid(h->n_cu, M, h->mf[0].ntile, &tps);
+		for (int g = 0; g < ep.ngroups; g++) {
+			const size_t lds = (size_t)2 * 16 * ep.gncol[g] * 16;
+			int *acc = h->mf_acc + ep.goff[g];
+#define MFRUN(NB, B1)                                                                          \
+	hipLaunchKernelGGL((score_mfma_kernel<NB, B1>), mgrid, dim3(WAVE * MF_WAVES), lds, st,     \
+		(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride)
+			const int nb = h->mf_nbfv[g];
+			if (g == 0) {
+				if (nb == 3) MFRUN(3, true); else if (nb == 4) MFRUN(4, true);
+				else return fail(SGX_EINVAL, "MFMA score path: unsupported group width %d", nb);
+			} else {
+				if (nb == 1) MFRUN(1, false); else if (nb == 2) MFRUN(2, false);
+				else if (nb == 3) MFRUN(3, false); else MFRUN(4, false);
+			}
+#undef MFRUN
 		}
-#undef MFCASE
+		switch (md.K) {
+#define ECASE(KK) case KK:                                                                     \
+	hipLaunchKernelGGL((score_mfma_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), \
+		0, st, (int)M, md, ep, h->mf_acc, h->recs, h->counters, out8, valid); break;
+		FOR_EACH_K(ECASE)
+#undef ECASE
+		default: return fail(SGX_EINVAL, "MFMA score path: unsupported K=%d", md.K);
+		}
 	} else {
 	const dim3 grid((unsigned)M);
 		switch (md.K) {
@@ -745,7 +773,7 @@ static int grm_matvec_dev(sgx_grm *g, const double *b, double *out)
 	HIPCHK(hipMemsetAsync(g->accV, 0, M * GRM_NACC * sizeof(int), st));
 	int tps = 0;
 	dim3 grid = grm_mfma_grid(g, M, g->tbN.ntile, &tps);
-	hipLaunchKernelGGL((score_mfma_kernel<1, false>), grid, dim3(WAVE * MF_WAVES), lds, st, g->G, g->bpvN, (int)M, g->tbN, tps, g->accV);
+	hipLaunchKernelGGL((score_mfma_kernel<1, false>), grid, dim3(WAVE * MF_WAVES), lds, st, g->G, g->bpvN, (int)M, g->tbN, tps, g->accV, GRM_NACC);
 	hipLaunchKernelGGL(grm_dot_epilogue, dim3(GRM_RED_BLOCKS), dim3(256), 0, st, M, g->accV, g->maxb, sum_b,
 		g->af, g->inv, g->l0, g->xv, g->gv, g->part);
 	HIPCHK(hipGetLastError());
@@ -759,7 +787,7 @@ static int grm_matvec_dev(sgx_grm *g, const double *b, double *out)
 	hipLaunchKernelGGL(limbs_kernel, dim3(512), dim3(256), 0, st, g->gv, M, (size_t)g->tbM.ntile * 256, MF_NLIMB, g->maxb + 2, g->FlM);
 	HIPCHK(hipMemsetAsync(g->accS, 0, N * GRM_NACC * sizeof(int), st));
 	grid = grm_mfma_grid(g, N, g->tbM.ntile, &tps);
-	hipLaunchKernelGGL((score_mfma_kernel<1, false>), grid, dim3(WAVE * MF_WAVES), lds, st, g->Gt, g->bpvM, g->N, g->tbM, tps, g->accS);
+	hipLaunchKernelGGL((score_mfma_kernel<1, false>), grid, dim3(WAVE * MF_WAVES), lds, st, g->Gt, g->bpvM, g->N, g->tbM, tps, g->accS, GRM_NACC);
 	hipLaunchKernelGGL(grm_out_epilogue, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, g->N, M, g->accS,
 		g->maxb + 1, g->maxb + 2, C0, out);
 	HIPCHK(hipGetLastError());
@@ -837,7 +865,6 @@ static int grm_init_impl(const uint8_t *packed, size_t bytes_per_marker, int32_t
 	GTRY(hipHostMalloc((void **)&g->h_part, GRM_RED_BLOCKS * sizeof(double), hipHostMallocDefault));
 	auto mk = [&](MfTab &tb, size_t n, uint8_t **Fl) -> hipError_t {
 		tb = MfTab{};
-		tb.nbfv = 1; tb.ncol = GRM_NCOL; tb.nacc = GRM_NACC;
 		tb.ntile = (int)((n + 255) / 256);
 		const size_t bytes = (size_t)tb.ntile * 16 * GRM_NCOL * 16;
 		hipError_t ee = hipMalloc((void **)Fl, bytes);

@@ -14,6 +14,7 @@
 #define LO_MASK 0x55555555u
 #include "../saigegds_amd/csrc/kern_synth.h"
 #define MF_KERNEL_ONLY
+#define SGX_MAX_COEFF 16
 #include "../saigegds_amd/csrc/kern_score_mfma.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -23,12 +24,12 @@ static float run(const uint8_t *G, size_t bpv, int M, const MfTab &tb, dim3 grid
 {
 	hipEvent_t a, b;
 	(void)hipEventCreate(&a); (void)hipEventCreate(&b);
-	const size_t lds = (size_t)2 * 16 * tb.ncol * 16 + ((ABL & 512) ? 16 * 1024 : 0);
+	const size_t lds = (size_t)2 * 16 * 80 * 16 + ((ABL & 512) ? 16 * 1024 : 0);
 	float best = 1e30f;
 	for (int r = 0; r < reps + 1; r++) {
-		(void)hipMemsetAsync(acc, 0, (size_t)M * tb.nacc * sizeof(int), 0);
+		(void)hipMemsetAsync(acc, 0, (size_t)M * (80 + 64) * sizeof(int), 0);
 		(void)hipEventRecord(a, 0);
-		hipLaunchKernelGGL((score_mfma_kernel<4, true, ABL>), grid, dim3(WAVE * MF_WAVES), lds, 0, G, bpv, M, tb, tps, acc);
+		hipLaunchKernelGGL((score_mfma_kernel<4, true, ABL>), grid, dim3(WAVE * MF_WAVES), lds, 0, G, bpv, M, tb, tps, acc, 80 + 64);
 		(void)hipEventRecord(b, 0);
 		(void)hipEventSynchronize(b);
 		float ms = 0;
@@ -47,13 +48,13 @@ int main(int argc, char **argv)
 	const size_t bpv = (size_t)((N + 511) / 512) * 128;
 	uint8_t *G, *Fl; uint32_t *thr; int *acc;
 	MfTab tb{};
-	tb.nbfv = 4; tb.ncol = 80; tb.nacc = 80 + 64; tb.col_ones = 63; tb.col_b1 = 64;
+	const int NCOL = 80, NACC = 80 + 64;   // one column group of 4 value fragments + the bit-1 fragment
 	tb.ntile = 2 * ((N + 511) / 512);
 	CK(hipMalloc((void **)&G, (size_t)M * bpv));
 	CK(hipMalloc((void **)&thr, (size_t)M * 3 * sizeof(uint32_t)));
 	const size_t dbg_bytes = (size_t)64 << 20;
-	CK(hipMalloc((void **)&acc, (size_t)M * tb.nacc * sizeof(int) + dbg_bytes));
-	const size_t flb = (size_t)tb.ntile * 16 * tb.ncol * 16;
+	CK(hipMalloc((void **)&acc, (size_t)M * NACC * sizeof(int) + dbg_bytes));
+	const size_t flb = (size_t)tb.ntile * 16 * NCOL * 16;
 	CK(hipMalloc((void **)&Fl, flb));
 	std::vector<uint8_t> hf(flb);
 	uint64_t x = 12345;
@@ -106,7 +107,7 @@ int main(int argc, char **argv)
 		const float ms = run<1024 + MF_STAMP_EXTRA>(G, bpv, M, tb, grid, tps, acc, 1);
 		const size_t nw = (size_t)grid.x * grid.y * MF_WAVES;
 		std::vector<unsigned long long> d(nw * 4);
-		CK(hipMemcpy(d.data(), (char *)acc + (size_t)M * tb.nacc * sizeof(int), nw * 32, hipMemcpyDeviceToHost));
+		CK(hipMemcpy(d.data(), (char *)acc + (size_t)M * NACC * sizeof(int), nw * 32, hipMemcpyDeviceToHost));
 		double w = 0, i = 0, c = 0, n = 0;
 		for (size_t k = 0; k < nw; k++) { w += d[4 * k]; i += d[4 * k + 1]; c += d[4 * k + 2]; n += d[4 * k + 3]; }
 		printf("stamped run %.3f ms: per wave and tile  barrier+wait %.0f  issue %.0f  compute %.0f cycles (tiles/wave %.1f)\n",
