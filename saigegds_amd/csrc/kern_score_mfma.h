@@ -39,10 +39,12 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 #endif
 #define MF_VPW (16 * MF_NAF) /* variants per wave                            */
 #define MF_VPB (MF_VPW * MF_WAVES)
-#define MF_NLIMB 7
-#define MF_GCOLS 9           /* value columns per column group: 9 x 7 limbs + 1 = 64 = 4 B fragments */
-#define MF_MAXP (2 * SGX_MAX_COEFF + 3)   /* value columns: c' (K), e (K), s, w, mu                 */
-#define MF_MAXG ((MF_MAXP + MF_GCOLS - 1) / MF_GCOLS)
+#define MF_NLIMB 7           /* limbs of a full-precision column (56-bit fixed point)              */
+#define MF_LIMB_A 5          /* limbs of the t_XVX_inv_XV columns (c'): see "Limb counts" below     */
+#define MF_LIMB_E 6          /* limbs of the w X columns (e)                                        */
+#define MF_GLIMBS 64         /* limb columns per column group = 4 B fragments                       */
+#define MF_MAXP (2 * SGX_MAX_COEFF + 2)   /* value columns: c' (K), e (K), s, w                     */
+#define MF_MAXG 4
 
 // what the contraction kernel needs of one column group
 struct MfTab {
@@ -50,17 +52,29 @@ struct MfTab {
 	int ntile;                 // number of 256-sample tiles = ngrp_pad / 16
 };
 
-// Column groups.  With K covariates the score stage needs 2K + 3 sums of 7 limbs each; a
-// workgroup's accumulators hold 4 B fragments (64 limb columns), so the value columns are cut
-// into groups of MF_GCOLS and the contraction kernel runs once per group over the same packed
-// rows (K <= 3: one group).  Group 0 also carries the constant-1 column and the bit-1 fragment.
-// Accumulator row of a variant = the groups' rows one after the other: goff[g] ints in, group g
-// has gncol[g] ints of value (+ bit-1) sums followed by 16 * nbfv[g] ints of missing-plane sums.
+// Limb counts.  s = G.(y-mu) and w = sum w_i G_i^2 carry 7 limbs (56 bits: below the rounding of a
+// double-precision dot product).  The covariate projections enter the statistics only through
+//     var2 = c'.XVX.c' + w - 2 e.c'      S = s - S_a.c'
+// where c' = (X'VX)^-1 X'V G is O(AF) for the intercept direction and O(1/sqrt(N)) otherwise,
+// XVX c' - e vanishes when the two weight vectors (no-K V, GLMM mu2) agree, and S_a = X'(y-mu) is
+// ~0 at the fit.  e therefore carries 6 limbs (48 bits) and the t_XVX_inv_XV columns 5 (40 bits):
+// measured effect on var2 <= 5e-14 relative and on S/sqrt(var2) <= 6e-16 (golden model and the
+// N = 100 000 synthetic model, tools/limb_sim.py) -- under the rounding noise of the reference's
+// own double sums, and 2000 x under the 1e-10 parity bar.  With K = 3 the value
+// columns then fill exactly 3 B fragments: 3*5 + 3*6 + 7 + 7 + 1 = 48.
+//
+// Column groups.  A workgroup's accumulators hold up to 4 B fragments (64 limb columns); with
+// more covariates the columns are cut into groups (never inside a column) and the contraction
+// kernel runs once per group over the same packed rows.  Group 0 carries s, w, the constant-1
+// column and the bit-1 fragment.  Accumulator row of a variant = the groups' rows one after the
+// other: goff[g] ints in, group g has gncol[g] ints of value (+ bit-1) sums followed by
+// 16 * nbfv[g] ints of missing-plane sums.
 struct MfEpi {
 	int ngroups, acc_stride;
 	int goff[MF_MAXG], gncol[MF_MAXG];
 	int col_ones;              // group 0: column of the constant 1
-	int col_b1;                // group 0: first column of the mu2 limbs in the bit-1 fragment
+	int col_b1;                // group 0: first column of the w limbs in the bit-1 fragment
+	unsigned char cgrp[MF_MAXP], ccol[MF_MAXP], climb[MF_MAXP];   // per value column: group, first limb column, limbs
 	int escale[MF_MAXP];       // F = q * 2^-escale
 	long long ftot_hi[MF_MAXP];// sum_i q[i,c] = hi * 2^32 + lo
 	long long ftot_lo[MF_MAXP];
@@ -271,14 +285,14 @@ __device__ __forceinline__ double hl_to_double(HiLo x) { return (double)x.hi * 4
 __device__ __forceinline__ HiLo hl(long long hi, long long lo) { HiLo x; x.hi = hi; x.lo = lo; return x; }
 __device__ __forceinline__ HiLo hl_axpy(long long a, HiLo x, HiLo y) { return hl(a * x.hi + y.hi, a * x.lo + y.lo); }
 
-// limb sums of one column -> HiLo
-__device__ __forceinline__ HiLo mf_limbs(const int *a)
+// limb sums of one column (nl <= 7 limbs) -> HiLo
+__device__ __forceinline__ HiLo mf_limbs(const int *a, int nl = MF_NLIMB)
 {
 	long long lo = 0, hi = 0;
 #pragma unroll
-	for (int l = 3; l >= 0; l--) lo = lo * 256 + a[l];
+	for (int l = 3; l >= 0; l--) lo = lo * 256 + (l < nl ? a[l] : 0);
 #pragma unroll
-	for (int l = MF_NLIMB - 1; l >= 4; l--) hi = hi * 256 + a[l];
+	for (int l = MF_NLIMB - 1; l >= 4; l--) hi = hi * 256 + (l < nl ? a[l] : 0);
 	return hl(hi, lo);
 }
 
@@ -289,7 +303,7 @@ score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf
 	SpaRec *__restrict__ recs, int *__restrict__ counters, double *__restrict__ out8,
 	uint8_t *__restrict__ valid)
 {
-	constexpr int P = 2 * K + 2, CW = P - 1;     // score columns; column CW carries G^2, column P is mu
+	constexpr int P = 2 * K + 2, CW = P - 1;     // score columns c' (K), e (K), s, w; column CW carries G^2
 	const int j = blockIdx.x * blockDim.x + threadIdx.x;
 	if (j >= M) return;
 	const int *a0 = accbuf + (size_t)j * ep.acc_stride;   // group 0: value plane + bit-1 fragment
@@ -303,14 +317,14 @@ score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf
 	double *o = out8 + (size_t)j * 8;
 	if (!h.pass) { nan_row(o); valid[j] = 0; return; }
 	const double imp = 2 * h.AF;
-	double acc[P + 1];
+	double acc[P];
 	HiLo Wm = hl(0, 0), T3m = hl(0, 0);
 #pragma unroll
-	for (int c = 0; c < P + 1; c++) {
-		const int g = c / MF_GCOLS, cc = (c - g * MF_GCOLS) * MF_NLIMB;
+	for (int c = 0; c < P; c++) {
+		const int g = ep.cgrp[c], cc = ep.ccol[c], nl = ep.climb[c];
 		const int *a = a0 + ep.goff[g];
-		const HiLo V = mf_limbs(a + cc);
-		const HiLo T3 = mf_limbs(a + ep.gncol[g] + cc);
+		const HiLo V = mf_limbs(a + cc, nl);
+		const HiLo T3 = mf_limbs(a + ep.gncol[g] + cc, nl);
 		const HiLo W = hl_axpy(-3, T3, V);
 		const double t3d = hl_to_double(T3);
 		double s;
@@ -340,7 +354,7 @@ score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf
 		const int slot = atomicAdd(&counters[0], 1);
 		SpaRec rr;
 		rr.j = j; rr.minus = h.minus; rr.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
-		rr.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); rr.has_gmu = 1; rr.sum_gmu = acc[P];
+		rr.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); rr.has_gmu = 0; rr.sum_gmu = 0;   // m1: SPA stage, carrier sums
 		rr.p_noadj = pn; rr.S = Ssc; rr.var2 = v2sc;
 		for (int k = 0; k < 4; k++) rr.lut[k] = h.lut[k];
 		for (int k = 0; k < KMAX; k++) rr.c[k] = (k < md.K) ? cbuf[k] : 0.0;

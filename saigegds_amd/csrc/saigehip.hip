@@ -194,22 +194,32 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		f[2 * K + 1] = w;
 	}
 	// fixed-point limb tables for the MFMA score path (binary and quantitative alike), one per
-	// column group (kern_score_mfma.h)
+	// column group (kern_score_mfma.h "Limb counts", "Column groups")
 	std::vector<int8_t> Fl;
 	std::vector<size_t> fl_off;
 	if ((double)N * 384.0 < 2147483647.0) {
 		MfEpi &ep = h->mfe;
-		const int PE = P + 1;                       // score columns + mu
-		const int CW = P - 1;                       // the column that carries G^2 (w)
+		const int CS = 2 * K, CW = 2 * K + 1;       // s, and the column that carries G^2 (w)
 		const int ngrp = (N + 15) / 16;
 		const int ntile = (ngrp + 15) / 16;
 		const size_t ngrp_pad = (size_t)ntile * 16;
-		ep.ngroups = (PE + MF_GCOLS - 1) / MF_GCOLS;
+		// pack the columns: s, w and the constant 1 first (group 0), then e, then c'
+		std::vector<int> order = {CS, CW};
+		for (int k = 0; k < K; k++) order.push_back(K + k);
+		for (int k = 0; k < K; k++) order.push_back(k);
+		int g = 0, used = 1, glimbs[MF_MAXG] = {0};   // group 0: one column for the constant 1
+		for (int c : order) {
+			const int nl = c >= 2 * K ? MF_NLIMB : (c >= K ? MF_LIMB_E : MF_LIMB_A);
+			if (used + nl > MF_GLIMBS) { glimbs[g] = used; g++; used = 0; }
+			ep.cgrp[c] = (unsigned char)g; ep.ccol[c] = (unsigned char)(used - (g == 0 ? 1 : 0)); ep.climb[c] = (unsigned char)nl;
+			used += nl;
+		}
+		glimbs[g] = used;
+		ep.ngroups = g + 1;
 		int off = 0;
 		size_t bytes = 0;
-		for (int g = 0; g < ep.ngroups; g++) {
-			const int cols = std::min(MF_GCOLS, PE - g * MF_GCOLS);
-			const int nb = (MF_NLIMB * cols + (g == 0 ? 1 : 0) + 15) / 16;
+		for (g = 0; g < ep.ngroups; g++) {
+			const int nb = (glimbs[g] + 15) / 16;
 			h->mf_nbfv[g] = nb;
 			ep.gncol[g] = 16 * (nb + (g == 0 ? 1 : 0));
 			ep.goff[g] = off;
@@ -219,29 +229,28 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 			h->mf[g].ntile = ntile;
 		}
 		ep.acc_stride = off;
-		ep.col_ones = MF_NLIMB * std::min(PE, MF_GCOLS);
+		ep.col_ones = glimbs[0] - 1;                // after group 0's value columns
 		ep.col_b1 = 16 * h->mf_nbfv[0];
 		Fl.assign(bytes, 0);
-		auto at = [&](int g, int i, int col) -> int8_t & {
-			return Fl[fl_off[g] + ((size_t)(i / 16) * ep.gncol[g] + col) * 16 + mf_pos(i % 16)];
+		auto at = [&](int gg, int i, int col) -> int8_t & {
+			return Fl[fl_off[gg] + ((size_t)(i / 16) * ep.gncol[gg] + col) * 16 + mf_pos(i % 16)];
 		};
-		for (int c = 0; c < PE; c++) {
-			const int g = c / MF_GCOLS, cc = (c - g * MF_GCOLS) * MF_NLIMB;
-			auto Fc = [&](int i) { return c < P ? F[(size_t)i * P + c] : m->mu[i]; };
+		for (int c = 0; c < P; c++) {
+			const int gg = ep.cgrp[c], cc = ep.ccol[c], nl = ep.climb[c];
 			double mx = 0;
-			for (int i = 0; i < N; i++) mx = std::max(mx, std::fabs(Fc(i)));
+			for (int i = 0; i < N; i++) mx = std::max(mx, std::fabs(F[(size_t)i * P + c]));
 			int ex = 0;
 			if (mx > 0) (void)std::frexp(mx, &ex);
-			ep.escale[c] = 54 - ex;
+			ep.escale[c] = 8 * nl - 2 - ex;
 			__int128 tot = 0;
 			for (int i = 0; i < N; i++) {
-				long long q = std::llrint(std::ldexp(Fc(i), ep.escale[c]));
+				long long q = std::llrint(std::ldexp(F[(size_t)i * P + c], ep.escale[c]));
 				tot += q;
 				long long rem = q;
-				for (int l = 0; l < MF_NLIMB; l++) {
-					long long d = (l < MF_NLIMB - 1) ? (((rem + 128) & 255) - 128) : rem;
+				for (int l = 0; l < nl; l++) {
+					long long d = (l < nl - 1) ? (((rem + 128) & 255) - 128) : rem;
 					rem = (rem - d) >> 8;
-					at(g, i, cc + l) = (int8_t)d;
+					at(gg, i, cc + l) = (int8_t)d;
 					if (c == CW) at(0, i, ep.col_b1 + l) = (int8_t)d;
 				}
 			}
@@ -395,8 +404,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride)
 			const int nb = h->mf_nbfv[g];
 			if (g == 0) {
-				if (nb == 3) MFRUN(3, true); else if (nb == 4) MFRUN(4, true);
-				else return fail(SGX_EINVAL, "MFMA score path: unsupported group width %d", nb);
+				if (nb == 2) MFRUN(2, true); else if (nb == 3) MFRUN(3, true); else MFRUN(4, true);
 			} else {
 				if (nb == 1) MFRUN(1, false); else if (nb == 2) MFRUN(2, false);
 				else if (nb == 3) MFRUN(3, false); else MFRUN(4, false);
