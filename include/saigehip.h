@@ -122,7 +122,8 @@ int sgx_scan_2bit(sgx_handle *h, const uint8_t *packed, size_t bytes_per_variant
 
 /* Same, all buffers already resident in this GPU's HBM (device pointers).
  * packed must be 16-byte aligned and bytes_per_variant a multiple of 64 with
- * bytes_per_variant >= sgx_row_stride(N) = 64*ceil(N/256).  Asynchronous on the handle's stream;
+ * bytes_per_variant >= sgx_row_stride(N) = 128*ceil(N/512) (a multiple of 64 that is not one of
+ * 128 is accepted and takes a slower load pattern).  Asynchronous on the handle's stream;
  * call sgx_sync() before reading results or stats. */
 int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev,
 	size_t bytes_per_variant, size_t n_variants, double *out8_dev,

@@ -2,6 +2,7 @@
 // contraction on the matrix cores (v_mfma_i32_16x16x64_i8).
 // Part of libsaigehip.so (single translation unit: saigehip.hip).
 #pragma once
+#include <type_traits>
 
 // Why a matrix formulation at all: with FP64 the dense score sums cost
 // 2(2K+2) flop per (variant, sample) against 0.25 B of input, i.e. they are
@@ -105,13 +106,14 @@ __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 // a missing code, which a wave decides with one ballot.
 // HAS_B1 = false drops the bit-1 plane and its fragment (the implicit-GRM products
 // of kern_grm.h only need the code plane and the missing plane).
+// WIDE: a lane fetches 2 x 16 B of each of its rows per PAIR of tiles (the two halves of one
+// 128-B line, by back-to-back instructions) instead of 16 B per tile: half as many lines in flight
+// per byte.  Needs bpv % 128 == 0 and even tile ranges (t0, t1 - t0, tb.ntile).
 // ABL: switches of the timing tool tools/mfma_ablate.hip (wrong results; the product uses 0):
 //   1 no missing plane, 2 no bit-1 MFMA, 4 no unpack, 16 no A loads, 32 no B DMA,
 //   64 no arithmetic at all (loads, DMA, LDS reads and barriers only),
-//   256 rows of a fragment stored as one contiguous KiB per tile (layout experiment),
-//   512 A rows fetched by LDS-DMA instead of into registers (values unused),
 //   1024 s_memtime stamps per tile, 2048 all loads and DMA of a tile issued in one burst at its start
-template <int NBFV, bool HAS_B1, int ABL = 0>
+template <int NBFV, bool HAS_B1, bool WIDE = false, int ABL = 0>
 __global__ void __launch_bounds__(WAVE * MF_WAVES, 8 / MF_WAVES)
 score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab tb,
 	int tiles_per_split, int *__restrict__ accbuf, int acc_stride)
@@ -119,6 +121,10 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 	constexpr int NBF = NBFV + (HAS_B1 ? 1 : 0);
 	constexpr int NCOL = 16 * NBF;
 	constexpr int TILE_BYTES = 16 * NCOL * 16;
+	constexpr int NDMA = (TILE_BYTES / 1024 + MF_WAVES - 1) / MF_WAVES;   // DMA instructions per wave and tile
+	constexpr int AW = WIDE ? 2 : 1;                                      // 16-B pieces of a row held per lane
+	constexpr bool SPREAD = !(ABL & (2048 | 16));   // one VMEM instruction per MFMA group (else: a burst at the tile start)
+	static_assert(AW * MF_NAF + NDMA <= 4 * MF_NAF, "more loads per tile than MFMA groups");
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // 2 x TILE_BYTES, nothing else
 	uint8_t *ldsB = smem;
 
@@ -147,73 +153,65 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 	}
 	bool saw_missing = false;   // wave-uniform
 
-	// row pointers advance by 64 B per tile; bpv is a multiple of 64 that covers every
-	// tile (sgx_row_stride), rows past M are clamped (their sums are never stored)
+	// this lane's 16 B of each of its rows in tile t: dwords 16t+4kg .. +3.  Row pointers advance by
+	// 64 B per tile; bpv is a multiple of 64 that covers every tile (sgx_row_stride), rows past M
+	// are clamped (their sums are never stored)
 	const uint8_t *rowp[MF_NAF];
 #pragma unroll
-	for (int f = 0; f < MF_NAF; f++) {
+	for (int f = 0; f < MF_NAF; f++)
 		rowp[f] = packed + (size_t)min(vbase + 16 * f + r, M - 1) * bpv + (size_t)t0 * 64 + 16 * kg;
-		if (ABL & 256) rowp[f] = packed + ((size_t)(min(vbase + 16 * f, M - 16) / 16) * tb.ntile + t0) * 1024 + lane * 16;
-	}
-
-	// B tile t -> LDS buffer (t & 1) by LDS-DMA: 1 KiB per wave-instruction, lane-linear
-	auto issue_B = [&](int t) {
-		if (ABL & 32) return;
+	auto load_A1 = [&](uint4 &dst, int f, int piece) {
+		if (ABL & 16) { dst = make_uint4(t0 + f, lane, wid, 0x01010101u); return; }
+		dst = *reinterpret_cast<const uint4 *>(rowp[f] + 64 * piece);
+		if (piece == AW - 1) rowp[f] += 64 * AW;
+	};
+	// one KiB of B tile t -> LDS buffer (t & 1) by LDS-DMA, lane-linear
+	auto dma_B1 = [&](int t, int i) {
+		const int k = wid + i * MF_WAVES;
+		if ((ABL & 32) || k >= TILE_BYTES / 1024) return;
 		const uint8_t *src = tb.Fl + (size_t)t * TILE_BYTES;
 		uint8_t *dst = ldsB + (size_t)(t & 1) * TILE_BYTES;
-#pragma unroll
-		for (int k = wid; k < TILE_BYTES / 1024; k += MF_WAVES)
-			__builtin_amdgcn_global_load_lds(
-				(const __attribute__((address_space(1))) void *)(src + (size_t)k * 1024 + lane * 16),
-				(__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
-	};
-	// this lane's 64 samples of each of its variants in tile t: dwords 16t+4kg .. +3
-	auto load_A = [&](uint4 (&a)[MF_NAF]) {
-#pragma unroll
-		for (int f = 0; f < MF_NAF; f++) {
-			if (ABL & 512) {   // experiment: the same bytes by LDS-DMA (into scratch LDS), values unused
-				__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)rowp[f],
-					(__attribute__((address_space(3))) void *)(smem + 2 * TILE_BYTES + (wid * MF_NAF + f) * 1024), 16, 0, 0);
-				rowp[f] += (ABL & 256) ? 1024 : 64;
-				a[f] = make_uint4(t0 + f, lane, wid, 0x01010101u);
-				continue;
-			}
-			if (ABL & 16) { a[f] = make_uint4(t0 + f, lane, wid, 0x01010101u); continue; }
-			a[f] = *reinterpret_cast<const uint4 *>(rowp[f]);
-			rowp[f] += (ABL & 256) ? 1024 : 64;
-		}
+		__builtin_amdgcn_global_load_lds(
+			(const __attribute__((address_space(1))) void *)(src + (size_t)k * 1024 + lane * 16),
+			(__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
 	};
 
-	uint4 acur[MF_NAF], anxt[MF_NAF];
-	if (t0 < t1) { load_A(acur); issue_B(t0); }
+	uint4 acur[MF_NAF][AW], anxt[MF_NAF][AW];
+	if (t0 < t1) {
+#pragma unroll
+		for (int f = 0; f < MF_NAF; f++)
+#pragma unroll
+			for (int p = 0; p < AW; p++) load_A1(acur[f][p], f, p);
+#pragma unroll
+		for (int i = 0; i < NDMA; i++) dma_B1(t0, i);
+	}
 	// ABL & 1024: s_memtime stamps -> cycles spent waiting at the tile barrier / issuing loads / computing
 	unsigned long long st_wait = 0, st_issue = 0, st_comp = 0, st_prev = 0;
 #define MF_STAMP(x) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(x) :: "memory")
 	if (ABL & 1024) MF_STAMP(st_prev);
-	for (int t = t0; t < t1; t++) {
+
+	// one 256-sample tile; HH = which of the AW row pieces it reads
+	auto tile = [&](int t, auto HH) {
+		constexpr int hh = decltype(HH)::value;
 		__syncthreads();   // tile t landed (each wave drained its own DMA), tile t-1 fully consumed
 		unsigned long long sa = 0, sb = 0;
 		if (ABL & 1024) { __builtin_amdgcn_sched_barrier(0); MF_STAMP(sa); __builtin_amdgcn_sched_barrier(0); st_wait += sa - st_prev; }
-		constexpr bool SPREAD = !(ABL & (2048 | 16 | 512));   // one VMEM instruction per MFMA group (else: all at the tile start)
-		const bool more = t + 1 < t1;
-		if (!SPREAD && more) { load_A(anxt); issue_B(t + 1); }
+		const bool more_B = t + 1 < t1;                  // there is a next tile
+		const bool more_A = t + (AW - hh) < t1;          // there is a next row piece set (fetched in the hh = 0 tile)
+		// loads of this tile, spread over its MFMA groups: the A pieces of the next tile (pair), then the next B tile
 		auto vmem_slot = [&](int idx) {
-			if (!SPREAD || !more) return;
-			if (idx < MF_NAF) {
-				anxt[idx] = *reinterpret_cast<const uint4 *>(rowp[idx]);
-				rowp[idx] += (ABL & 256) ? 1024 : 64;
+			if (hh == 0 && idx < AW * MF_NAF) {
+				if (more_A) load_A1(anxt[idx / AW][idx % AW], idx / AW, idx % AW);
 			} else {
-				const int k = wid + (idx - MF_NAF) * MF_WAVES;
-				if (!(ABL & 32) && k < TILE_BYTES / 1024) {
-					const uint8_t *src = tb.Fl + (size_t)(t + 1) * TILE_BYTES;
-					uint8_t *dst = ldsB + (size_t)((t + 1) & 1) * TILE_BYTES;
-					__builtin_amdgcn_global_load_lds(
-						(const __attribute__((address_space(1))) void *)(src + (size_t)k * 1024 + lane * 16),
-						(__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
-				}
+				const int i = idx - (hh == 0 ? AW * MF_NAF : 0);
+				if (i < NDMA && more_B) dma_B1(t + 1, i);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 		};
+		if (!SPREAD) {
+#pragma unroll
+			for (int idx = 0; idx < 4 * MF_NAF; idx++) vmem_slot(idx);
+		}
 		if (ABL & 1024) { __builtin_amdgcn_sched_barrier(0); MF_STAMP(sb); __builtin_amdgcn_sched_barrier(0); st_issue += sb - sa; }
 		const uint8_t *bt = ldsB + (size_t)(t & 1) * TILE_BYTES;
 #pragma unroll
@@ -225,8 +223,9 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 				bfrag[b] = *reinterpret_cast<const v4i *>(bt + ((size_t)(g * NCOL + b * 16 + r)) * 16);
 #pragma unroll
 			for (int f = 0; f < MF_NAF; f++) {
-				const uint32_t w = (u == 0) ? acur[f].x : (u == 1) ? acur[f].y : (u == 2) ? acur[f].z : acur[f].w;
-				vmem_slot(u * MF_NAF + f);
+				const uint4 aw = acur[f][hh];
+				const uint32_t w = (u == 0) ? aw.x : (u == 1) ? aw.y : (u == 2) ? aw.z : aw.w;
+				if (SPREAD) vmem_slot(u * MF_NAF + f);
 				if (ABL & 64) { acc[f][0][0] ^= (int)w ^ bfrag[0][0]; continue; }
 				v4i val, b1;
 				if (ABL & 4) { val = (v4i){(int)w, (int)w, (int)w, (int)w}; b1 = val; }
@@ -249,8 +248,20 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 			}
 		}
 		if (ABL & 1024) { __builtin_amdgcn_sched_barrier(0); MF_STAMP(st_prev); __builtin_amdgcn_sched_barrier(0); st_comp += st_prev - sb; }
+		if (hh == AW - 1) {
 #pragma unroll
-		for (int f = 0; f < MF_NAF; f++) acur[f] = anxt[f];
+			for (int f = 0; f < MF_NAF; f++)
+#pragma unroll
+				for (int p = 0; p < AW; p++) acur[f][p] = anxt[f][p];
+		}
+	};
+	if (WIDE) {
+		for (int t = t0; t < t1; t += 2) {
+			tile(t, std::integral_constant<int, 0>());
+			tile(t + 1, std::integral_constant<int, AW - 1>());
+		}
+	} else {
+		for (int t = t0; t < t1; t++) tile(t, std::integral_constant<int, 0>());
 	}
 	if ((ABL & 1024) && lane == 0) {
 		unsigned long long *dbg = reinterpret_cast<unsigned long long *>(accbuf + (size_t)M * acc_stride) +

@@ -125,7 +125,7 @@ extern "C" int sgx_device_count(void)
 
 extern "C" size_t sgx_row_stride(int32_t n_samp)
 {
-	return (size_t)((n_samp + 255) / 256) * 64;   // whole 256-sample tiles (kern_score_mfma.h)
+	return (size_t)((n_samp + 511) / 512) * 128;  // whole pairs of 256-sample tiles = whole 128-B lines (kern_score_mfma.h)
 }
 
 static double thr_or(double v, double dflt) { return std::isfinite(v) ? v : dflt; }
@@ -201,7 +201,7 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		MfEpi &ep = h->mfe;
 		const int CS = 2 * K, CW = 2 * K + 1;       // s, and the column that carries G^2 (w)
 		const int ngrp = (N + 15) / 16;
-		const int ntile = (ngrp + 15) / 16;
+		const int ntile = 2 * ((ngrp + 31) / 32);   // even: the wide-row kernel walks pairs of tiles
 		const size_t ngrp_pad = (size_t)ntile * 16;
 		// pack the columns: s, w and the constant 1 first (group 0), then e, then c'
 		std::vector<int> order = {CS, CW};
@@ -374,8 +374,9 @@ static dim3 mf_grid(int n_cu, size_t rows, int ntile, int *tps)
 	const int vt = (int)((rows + MF_VPB - 1) / MF_VPB);
 	int sk = std::max(1, (n_cu * 2 * 4 + vt / 2) / vt);
 	if (sk >= 6) sk = (sk + 7) & ~7;
-	sk = std::min(sk, ntile);
+	sk = std::min(sk, std::max(1, ntile / 2));
 	*tps = (ntile + sk - 1) / sk;
+	*tps += *tps & 1;                         // even tile ranges (wide-row kernel)
 	sk = (ntile + *tps - 1) / *tps;
 	return dim3((unsigned)vt, (unsigned)sk);
 }
@@ -396,12 +397,15 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		HIPCHK(hipMemsetAsync(h->mf_acc, 0, M * (size_t)ep.acc_stride * sizeof(int), st));
 		int tps = 0;
 		const dim3 mgrid = mf_grid(h->n_cu, M, h->mf[0].ntile, &tps);
+		const bool wide = row_bytes % 128 == 0 && (size_t)h->mf[0].ntile * 64 <= row_bytes;   // else 16 B per row and tile
 		for (int g = 0; g < ep.ngroups; g++) {
 			const size_t lds = (size_t)2 * 16 * ep.gncol[g] * 16;
 			int *acc = h->mf_acc + ep.goff[g];
 #define MFRUN(NB, B1)                                                                          \
-	hipLaunchKernelGGL((score_mfma_kernel<NB, B1>), mgrid, dim3(WAVE * MF_WAVES), lds, st,     \
-		(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride)
+	do { if (wide) hipLaunchKernelGGL((score_mfma_kernel<NB, B1, true>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
+			(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride);      \
+		else hipLaunchKernelGGL((score_mfma_kernel<NB, B1, false>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
+			(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride); } while (0)
 			const int nb = h->mf_nbfv[g];
 			if (g == 0) {
 				if (nb == 2) MFRUN(2, true); else if (nb == 3) MFRUN(3, true); else MFRUN(4, true);
@@ -781,7 +785,7 @@ static int grm_matvec_dev(sgx_grm *g, const double *b, double *out)
 	HIPCHK(hipMemsetAsync(g->accV, 0, M * GRM_NACC * sizeof(int), st));
 	int tps = 0;
 	dim3 grid = grm_mfma_grid(g, M, g->tbN.ntile, &tps);
-	hipLaunchKernelGGL((score_mfma_kernel<1, false>), grid, dim3(WAVE * MF_WAVES), lds, st, g->G, g->bpvN, (int)M, g->tbN, tps, g->accV, GRM_NACC);
+	hipLaunchKernelGGL((score_mfma_kernel<1, false, true>), grid, dim3(WAVE * MF_WAVES), lds, st, g->G, g->bpvN, (int)M, g->tbN, tps, g->accV, GRM_NACC);
 	hipLaunchKernelGGL(grm_dot_epilogue, dim3(GRM_RED_BLOCKS), dim3(256), 0, st, M, g->accV, g->maxb, sum_b,
 		g->af, g->inv, g->l0, g->xv, g->gv, g->part);
 	HIPCHK(hipGetLastError());
@@ -795,7 +799,7 @@ static int grm_matvec_dev(sgx_grm *g, const double *b, double *out)
 	hipLaunchKernelGGL(limbs_kernel, dim3(512), dim3(256), 0, st, g->gv, M, (size_t)g->tbM.ntile * 256, MF_NLIMB, g->maxb + 2, g->FlM);
 	HIPCHK(hipMemsetAsync(g->accS, 0, N * GRM_NACC * sizeof(int), st));
 	grid = grm_mfma_grid(g, N, g->tbM.ntile, &tps);
-	hipLaunchKernelGGL((score_mfma_kernel<1, false>), grid, dim3(WAVE * MF_WAVES), lds, st, g->Gt, g->bpvM, g->N, g->tbM, tps, g->accS, GRM_NACC);
+	hipLaunchKernelGGL((score_mfma_kernel<1, false, true>), grid, dim3(WAVE * MF_WAVES), lds, st, g->Gt, g->bpvM, g->N, g->tbM, tps, g->accS, GRM_NACC);
 	hipLaunchKernelGGL(grm_out_epilogue, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, g->N, M, g->accS,
 		g->maxb + 1, g->maxb + 2, C0, out);
 	HIPCHK(hipGetLastError());
@@ -857,7 +861,7 @@ static int grm_init_impl(const uint8_t *packed, size_t bytes_per_marker, int32_t
 	const size_t N = (size_t)n_samp, M = n_markers;
 	g->N = n_samp; g->M = M;
 	g->bpvN = sgx_row_stride(n_samp);
-	g->bpvM = (size_t)((M + 255) / 256) * 64;
+	g->bpvM = (size_t)((M + 511) / 512) * 128;
 	GTRY(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
 	GTRY(hipMalloc((void **)&g->G, M * g->bpvN));
 	GTRY(hipMalloc((void **)&g->Gt, N * g->bpvM));
@@ -873,7 +877,7 @@ static int grm_init_impl(const uint8_t *packed, size_t bytes_per_marker, int32_t
 	GTRY(hipHostMalloc((void **)&g->h_part, GRM_RED_BLOCKS * sizeof(double), hipHostMallocDefault));
 	auto mk = [&](MfTab &tb, size_t n, uint8_t **Fl) -> hipError_t {
 		tb = MfTab{};
-		tb.ntile = (int)((n + 255) / 256);
+		tb.ntile = 2 * (int)((n + 511) / 512);
 		const size_t bytes = (size_t)tb.ntile * 16 * GRM_NCOL * 16;
 		hipError_t ee = hipMalloc((void **)Fl, bytes);
 		if (ee != hipSuccess) return ee;

@@ -50,7 +50,7 @@ def synth_packed(n_samp: int, first_variant: int, n_variants: int, seed: int, th
     """numpy twin of ``sgx_synth_2bit_dev`` -> packed [M, bytes_per_variant]."""
     from .gds import pack_dosage_2bit
     if bytes_per_variant is None:
-        bytes_per_variant = ((n_samp + 255) // 256) * 64
+        bytes_per_variant = ((n_samp + 511) // 512) * 128
     out = np.zeros((n_variants, bytes_per_variant), dtype=np.uint8)
     i = np.arange(n_samp, dtype=np.uint64)
     with np.errstate(over="ignore"):

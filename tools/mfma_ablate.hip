@@ -19,17 +19,17 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-template <int ABL>
+template <int ABL, bool WIDE = false>
 static float run(const uint8_t *G, size_t bpv, int M, const MfTab &tb, dim3 grid, int tps, int *acc, int reps)
 {
 	hipEvent_t a, b;
 	(void)hipEventCreate(&a); (void)hipEventCreate(&b);
-	const size_t lds = (size_t)2 * 16 * 80 * 16 + ((ABL & 512) ? 16 * 1024 : 0);
+	const size_t lds = (size_t)2 * 16 * 64 * 16 + ((ABL & 512) ? 16 * 1024 : 0);
 	float best = 1e30f;
 	for (int r = 0; r < reps + 1; r++) {
-		(void)hipMemsetAsync(acc, 0, (size_t)M * (80 + 64) * sizeof(int), 0);
+		(void)hipMemsetAsync(acc, 0, (size_t)M * (64 + 48) * sizeof(int), 0);
 		(void)hipEventRecord(a, 0);
-		hipLaunchKernelGGL((score_mfma_kernel<4, true, ABL>), grid, dim3(WAVE * MF_WAVES), lds, 0, G, bpv, M, tb, tps, acc, 80 + 64);
+		hipLaunchKernelGGL((score_mfma_kernel<3, true, WIDE, ABL>), grid, dim3(WAVE * MF_WAVES), lds, 0, G, bpv, M, tb, tps, acc, 64 + 48);
 		(void)hipEventRecord(b, 0);
 		(void)hipEventSynchronize(b);
 		float ms = 0;
@@ -48,7 +48,7 @@ int main(int argc, char **argv)
 	const size_t bpv = (size_t)((N + 511) / 512) * 128;
 	uint8_t *G, *Fl; uint32_t *thr; int *acc;
 	MfTab tb{};
-	const int NCOL = 80, NACC = 80 + 64;   // one column group of 4 value fragments + the bit-1 fragment
+	const int NCOL = 64, NACC = 64 + 48;   // the K = 3 layout: 3 value fragments + the bit-1 fragment
 	tb.ntile = 2 * ((N + 511) / 512);
 	CK(hipMalloc((void **)&G, (size_t)M * bpv));
 	CK(hipMalloc((void **)&thr, (size_t)M * 3 * sizeof(uint32_t)));
@@ -77,7 +77,8 @@ int main(int argc, char **argv)
 	int sk = std::max(1, (pr.multiProcessorCount * (8 / MF_WAVES) * 4 + vt / 2) / vt);
 	if (sk >= 6) sk = (sk + 7) & ~7;
 	sk = std::min(sk, tb.ntile);
-	const int tps = (tb.ntile + sk - 1) / sk;
+	int tps = (tb.ntile + sk - 1) / sk;
+	tps += tps & 1;
 	sk = (tb.ntile + tps - 1) / tps;
 	const dim3 grid(vt, sk);
 	printf("N=%d M=%d grid=(%d,%d) tiles/split=%d bytes=%.3f GB\n", N, M, vt, sk, tps, (double)M * bpv / 1e9);
@@ -86,23 +87,23 @@ int main(int argc, char **argv)
 	RUN(0, "product kernel")
 	RUN(1, "- missing plane")
 	RUN(2, "- bit-1 MFMA")
-	RUN(3, "- missing plane, bit-1 MFMA")
 	RUN(4, "- unpack")
 	RUN(16, "- A loads")
 	RUN(32, "- B DMA")
 	RUN(48, "- A loads, B DMA")
-	RUN(60, "- all but MFMA + missing test")
 	RUN(63, "value-plane MFMA only")
 	RUN(64, "memory system only")
 	RUN(96, "A loads + barriers only")
 	RUN(2048, "loads of a tile in one burst")
-	RUN(2304, "same, tiled rows")
-	RUN(512, "product but A by LDS-DMA (unused)")
-	RUN(768, "same, tiled rows")
-	RUN(256, "product, tiled rows")
-	RUN(257, "tiled rows, - missing plane")
-	RUN(320, "memory system only, tiled rows")
-	RUN(352, "A loads + barriers only, tiled")
+#define RUNW(A, what) { const float ms = run<A, true>(G, bpv, M, tb, grid, tps, acc, reps); \
+	printf("ABL=%2d wide rows: %-22s %7.3f ms  %6.0f GB/s\n", A, what, ms, (double)M * bpv / ms / 1e6); }
+	if (tps % 2 == 0 && tb.ntile % 2 == 0) {
+		RUNW(0, "product kernel")
+		RUNW(1, "- missing plane")
+		RUNW(64, "memory system only")
+		RUNW(96, "A loads + barriers")
+		RUNW(2048, "loads in one burst")
+	}
 	{   // where a wave's cycles go (s_memtime stamps; the stamps themselves cost a few %)
 		const float ms = run<1024 + MF_STAMP_EXTRA>(G, bpv, M, tb, grid, tps, acc, 1);
 		const size_t nw = (size_t)grid.x * grid.y * MF_WAVES;
