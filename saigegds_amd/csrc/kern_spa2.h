@@ -27,6 +27,7 @@ struct RootState {
 	double K2cur;      // K2 sum at t
 	double Kcur;       // Korg sum at t (valid when k_ok)
 	double prevJump;
+	double st_prev;    // size of the previous Newton step (for the last-evaluation guess only)
 	double tnew;       // point being evaluated
 	int it;
 	int phase;         // 0 first evaluation at t=0, 1 Newton candidate, 2 bisected candidate
@@ -44,7 +45,7 @@ __device__ __forceinline__ void root_begin(RootState &s, double q, double g_pos_
 {
 	s.q = q; s.t = 0; s.root = 0; s.K1_eval = 0; s.K2cur = 0; s.Kcur = 0; s.prevJump = INFINITY;
 	s.tnew = 0; s.it = 1; s.phase = 0; s.active = true; s.converged = false;
-	s.want_k = false; s.k_ok = false;
+	s.want_k = false; s.k_ok = false; s.st_prev = 0;
 	(void)g_pos_lb; (void)g_neg_ub;
 }
 
@@ -60,8 +61,12 @@ __device__ __forceinline__ void root_step(RootState &s, double NAsigma)
 	// Newton converges quadratically: if the step after this one is predicted to fall under
 	// the tolerance, this evaluation is the last and its point becomes the root, so Korg is
 	// wanted with it (a wrong guess only costs time: spa3_korg covers the rest)
+	// Steps shrink like st' ~ C st^2 with C ~ st / st_prev^2 once two steps are known.  A guess on
+	// the generous side is cheap (one log per carrier), a missed one costs a sweep over the list.
 	const double st = fabs(tnew - s.t);
-	s.want_k = st * st < 8.0 * SPA_TOL * fmax(fabs(tnew), 1e-3);
+	const double next = (s.st_prev > 0) ? st * st * st / (s.st_prev * s.st_prev) : st * st / (8.0 * fmax(fabs(tnew), 1e-3));
+	s.want_k = next < 1.5 * SPA_TOL;
+	s.st_prev = st;
 }
 
 // consume the sums evaluated at s.tnew, SPATest.cpp:152,166-181
