@@ -8,12 +8,14 @@
 // Newton iteration of ALL flagged variants advances in lock step and every
 // launch is balanced over fixed-size pieces of the carrier lists:
 //
-//   spa3_count  carriers per (variant, 8192-sample segment)
+//   spa3_count  carriers per (variant, sample segment); segment = as many samples as have their
+//               X rows and mu in 128 KiB of LDS (4096 at K = 3)
 //   spa3_plan   per variant: scalars that need no carrier pass (m1, q~, the
 //               cutoff exit of SPATest.cpp:319-321),
 //               exclusive scan over its segments, arena allocation
-//   spa3_fill   per (variant, segment): gather X_i, mu_i -> (adj, mu) entries at
-//               their final arena position (ascending sample order), carrier sums
+//   spa3_fill   per (segment, slice of the variants): the segment's X rows and mu are staged in
+//               LDS once, then one wave per variant turns its carriers into (adj, mu) entries at
+//               their final arena position (ascending sample order) and forms the carrier sums
 //   spa3_head   per variant: ordered sums, g_pos/g_neg bound test, the Newton
 //               step at t = 0, chunk descriptors
 //   repeat L times
@@ -42,7 +44,8 @@
 #define SPA3_CHUNK 4096      /* carriers per chunk                     */
 #define SPA3_BLOCK 256
 #define SPA3_MLP 4           /* independent 16-byte loads in flight per thread */
-#define SPA3_SEG 8192        /* samples per extraction segment = 512 dwords */
+#define SPA3_TAB_BYTES (128 * 1024)   /* LDS for the X rows + mu of one sample segment */
+#define SPA3_FILL_WAVES 16
 #define SPA3_NPART 6         /* doubles per chunk partial: K1a K2a Ka K1b K2b Kb */
 #define SPA3_NSEGP 6         /* doubles per (variant, segment): the carrier sums */
 
@@ -91,32 +94,36 @@ __device__ __forceinline__ void cgf_terms(double g, double m, double t, double &
 // counters: [0] n_spa [1] n_valid [2] n_dense_fallback [3] n_spa2_fallback
 //           [4] chunk cursor [6] number of valid chunk descriptors
 
+// samples per extraction segment for K covariates: rows of (K + 2) & ~1 doubles, a power of two
+// of them in SPA3_TAB_BYTES, at most 4096
+__host__ __device__ constexpr int spa3_seg(int K)
+{
+	const int row = ((K + 2) & ~1) * 8;
+	return row <= 32 ? 4096 : row <= 64 ? 2048 : row <= 128 ? 1024 : 512;
+}
+
+// one wave per (variant, segment)
 __global__ void __launch_bounds__(256)
-spa3_count(const uint8_t *__restrict__ packed, size_t bpv, int N, int nseg,
+spa3_count(const uint8_t *__restrict__ packed, size_t bpv, int N, int nseg, int seg_samples,
 	const SpaRec *__restrict__ recs, const int *__restrict__ counters, int *__restrict__ segcnt)
 {
-	__shared__ int shi[4];
-	const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	const int lane = threadIdx.x & (WAVE - 1);
+	const int gw = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, nw = gridDim.x * blockDim.x / WAVE;
 	const int nflag = counters[0];
 	const int nitem = nflag * nseg;
-	const int ndw = (N + 15) >> 4;
-	for (int wi = blockIdx.x; wi < nitem; wi += gridDim.x) {
+	const int ndw = (N + 15) >> 4, segdw = seg_samples / 16;
+	for (int wi = gw; wi < nitem; wi += nw) {
 		const int seg = wi / nflag, v = wi - seg * nflag;   // segment-major order
-		const int it = v * nseg + seg;
 		const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (size_t)recs[v].j * bpv);
 		const uint32_t zx = recs[v].minus ? 0xAAAAAAAAu : 0u;
 		int cnt = 0;
-#pragma unroll
-		for (int u = 0; u < 2; u++) {
-			const int d = seg * (SPA3_SEG / 16) + 2 * tid + u;
+		for (int dd = lane; dd < segdw; dd += WAVE) {
+			const int d = seg * segdw + dd;
 			const uint32_t w = (d < ndw) ? row[d] : 0u;
 			cnt += __popc(nz_fields((w ^ zx) & keep_mask(N - d * 16)));
 		}
 		cnt = wave_sum_i(cnt);
-		__syncthreads();
-		if (lane == 0) shi[wid] = cnt;
-		__syncthreads();
-		if (tid == 0) segcnt[it] = shi[0] + shi[1] + shi[2] + shi[3];
+		if (lane == 0) segcnt[v * nseg + seg] = cnt;
 	}
 }
 
@@ -167,96 +174,131 @@ spa3_plan(DevModel md, int nseg, const SpaRec *__restrict__ recs, int *__restric
 	heads[v] = h;
 }
 
+// grid-stride over (segment, slice of the flagged variants), segment-major; block = SPA3_FILL_WAVES
+// waves; dynamic LDS = the segment's table + one 1024-entry queue per wave.
 template <int K>
-__global__ void __launch_bounds__(256)
-spa3_fill(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg,
+__global__ void __launch_bounds__(WAVE * SPA3_FILL_WAVES)
+spa3_fill(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg, int nslice,
 	const SpaRec *__restrict__ recs, const int *__restrict__ counters, const int *__restrict__ segoff,
 	const SpaHead *__restrict__ heads, double2 *__restrict__ arena, double *__restrict__ segpart)
 {
-	constexpr int BLOCK = 256, NW = BLOCK / WAVE;
-	constexpr int KP = (K + 2) & ~1;
-	__shared__ double sh[SPA3_NSEGP * NW];
-	__shared__ int shi[NW];
-	__shared__ uint32_t qidx[SPA3_SEG];
+	constexpr int SEG = spa3_seg(K), KP = (K + 2) & ~1;
+	constexpr int SUBDW = SEG / 16 < WAVE ? SEG / 16 : WAVE, NSUB = SEG / 16 / SUBDW;   // dwords per sub-step (one per lane)
+	constexpr int FMLP = K <= 4 ? 4 : (K <= 8 ? 2 : 1);   // carriers per lane in flight (registers: K + 1 doubles each)
+	extern __shared__ __attribute__((aligned(16))) uint8_t fill_smem[];
+	double *tab = reinterpret_cast<double *>(fill_smem);                               // [SEG][KP]
+	uint16_t *queues = reinterpret_cast<uint16_t *>(fill_smem + (size_t)SEG * KP * 8);    // [waves][1024]
 	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	uint16_t *q = queues + wid * 1024;       // sample within the segment (12 bits) | code << 14
 	const int nflag = counters[0];
-	const int nitem = nflag * nseg;
+	const int vper = (nflag + nslice - 1) / nslice;
 	const int ndw = (N + 15) >> 4;
-	for (int wi = blockIdx.x; wi < nitem; wi += gridDim.x) {
-		// segment-major: workgroups running together gather the same 8192 rows of XM (L2)
-		const int seg = wi / nflag, v = wi - seg * nflag;
-		const int it = v * nseg + seg;
-		const SpaHead *hd = heads + v;
-		if (hd->nnz < 0) continue;
-		const SpaRec r = recs[v];
-		const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (size_t)r.j * bpv);
-		const double inv = 1 / sqrt(r.AC2);
-		const uint32_t zx = r.minus ? 0xAAAAAAAAu : 0u;
-		double c[K];
-#pragma unroll
-		for (int a = 0; a < K; a++) c[a] = r.c[a];
-		const int d0 = seg * (SPA3_SEG / 16) + 2 * tid;
-		uint32_t w[2], nz[2];
-		int cnt = 0;
-#pragma unroll
-		for (int u = 0; u < 2; u++) {
-			w[u] = (d0 + u < ndw) ? row[d0 + u] : 0u;
-			nz[u] = nz_fields((w[u] ^ zx) & keep_mask(N - (d0 + u) * 16));
-			cnt += __popc(nz[u]);
-		}
-		int incl = cnt;
-#pragma unroll
-		for (int o = 1; o < WAVE; o <<= 1) {
-			const int up = __shfl_up(incl, o, WAVE);
-			if (lane >= o) incl += up;
-		}
-		__syncthreads();                     // previous item's readers of shi / qidx are done
-		if (lane == WAVE - 1) shi[wid] = incl;
-		__syncthreads();
-		int wbase = 0, total = 0;
-#pragma unroll
-		for (int ww = 0; ww < NW; ww++) { if (ww < wid) wbase += shi[ww]; total += shi[ww]; }
-		int o2 = wbase + incl - cnt;
-#pragma unroll
-		for (int u = 0; u < 2; u++) {
-			uint32_t z = nz[u];
-			while (z) {
-				const int b = __ffs(z) - 1;
-				z &= z - 1;
-				qidx[o2++] = (uint32_t)((d0 + u) * 16 + (b >> 1)) | (((w[u] >> b) & 3u) << 30);
-			}
+	for (int item = blockIdx.x; item < nseg * nslice; item += gridDim.x) {
+		const int seg = item / nslice, sl = item - seg * nslice;
+		const int vbeg = sl * vper, vend = min(nflag, vbeg + vper);
+		if (vbeg >= vend) continue;
+		__syncthreads();                     // the previous item's readers of the table are done
+		{
+			const int rows = min(SEG, N - seg * SEG);
+			const double2 *src = reinterpret_cast<const double2 *>(md.XM + (size_t)seg * SEG * KP);
+			double2 *dst = reinterpret_cast<double2 *>(tab);
+			for (int i = tid; i < rows * (KP / 2); i += WAVE * SPA3_FILL_WAVES) dst[i] = src[i];
 		}
 		__syncthreads();
-		double2 *lst = arena + hd->off + (unsigned long long)segoff[it];
-		// 0 sum mu*G, 1 sum b, 2 sum max(adj,0), 3 sum min(adj,0), 4 sum adj*mu, 5 sum adj^2 mu(1-mu)
-		double a12[SPA3_NSEGP];
+		// this lane's dwords of a variant's segment (one per sub-step), fetched one variant ahead
+		auto load_row = [&](int v, uint32_t (&wv)[NSUB]) {
+			const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (size_t)recs[v].j * bpv);
 #pragma unroll
-		for (int a = 0; a < SPA3_NSEGP; a++) a12[a] = 0;
-		for (int k = tid; k < total; k += BLOCK) {
-			const uint32_t e = qidx[k];
-			const int i = (int)(e & 0x3FFFFFFFu);
-			const double G = sel4(r.lut, e >> 30);
-			const double *x = md.XM + (size_t)i * KP;
-			double xv[KP];
-#pragma unroll
-			for (int a = 0; a < KP; a += 2) {
-				const double2 t2 = *reinterpret_cast<const double2 *>(x + a);
-				xv[a] = t2.x; xv[a + 1] = t2.y;
+			for (int sub = 0; sub < NSUB; sub++) {
+				const int d = seg * (SEG / 16) + sub * SUBDW + lane;
+				wv[sub] = (lane < SUBDW && d < ndw) ? row[d] : 0u;
 			}
-			double b = 0;
+		};
+		uint32_t wcur[NSUB], wnxt[NSUB];
+		if (vbeg + wid < vend) load_row(vbeg + wid, wcur);
+		for (int v = vbeg + wid; v < vend; v += SPA3_FILL_WAVES) {
+			if (v + SPA3_FILL_WAVES < vend) load_row(v + SPA3_FILL_WAVES, wnxt);
+			uint32_t wrow[NSUB];
 #pragma unroll
-			for (int a = 0; a < K; a++) b = fma(xv[a], c[a], b);
-			const double mui = xv[K];
-			const double adj = (G - b) * inv;
-			lst[k] = make_double2(adj, mui);
-			a12[0] = fma(mui, G, a12[0]);
-			a12[1] += b;
-			if (adj > 0) a12[2] += adj; else a12[3] += adj;
-			a12[4] = fma(adj, mui, a12[4]);
-			a12[5] = fma(adj * adj, mui * (1 - mui), a12[5]);
+			for (int sub = 0; sub < NSUB; sub++) { wrow[sub] = wcur[sub]; wcur[sub] = wnxt[sub]; }
+			const SpaHead *hd = heads + v;
+			if (hd->nnz < 0) continue;
+			const SpaRec r = recs[v];
+			const int it = v * nseg + seg;
+			const double inv = 1 / sqrt(r.AC2);
+			const uint32_t zx = r.minus ? 0xAAAAAAAAu : 0u;
+			double c[K];
+#pragma unroll
+			for (int a = 0; a < K; a++) c[a] = r.c[a];
+			double2 *lst = arena + hd->off + (unsigned long long)segoff[it];
+			// 0 sum mu*G, 1 sum b, 2 sum max(adj,0), 3 sum min(adj,0), 4 sum adj*mu, 5 sum adj^2 mu(1-mu)
+			double a12[SPA3_NSEGP];
+#pragma unroll
+			for (int a = 0; a < SPA3_NSEGP; a++) a12[a] = 0;
+			int run = 0;
+#pragma unroll
+			for (int sub = 0; sub < NSUB; sub++) {
+				// 16 SUBDW samples: one dword per lane -> carriers, compacted through the wave's queue
+				const int d = seg * (SEG / 16) + sub * SUBDW + lane;
+				const bool mine = lane < SUBDW && d < ndw;       // (a flipped variant turns an absent dword into carriers)
+				const uint32_t w = wrow[sub];
+				uint32_t z = mine ? nz_fields((w ^ zx) & keep_mask(N - d * 16)) : 0u;
+				const int cnt = __popc(z);
+				int incl = cnt;
+#pragma unroll
+				for (int o = 1; o < WAVE; o <<= 1) {
+					const int up = __shfl_up(incl, o, WAVE);
+					if (lane >= o) incl += up;
+				}
+				const int total = __shfl(incl, WAVE - 1, WAVE);
+				int o2 = incl - cnt;
+				while (z) {
+					const int b = __ffs(z) - 1;
+					z &= z - 1;
+					q[o2++] = (uint16_t)((sub * SUBDW + lane) * 16 + (b >> 1)) | (uint16_t)(((w >> b) & 3u) << 14);
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own LDS writes, in order
+				__builtin_amdgcn_wave_barrier();
+				for (int k0 = lane; k0 < total; k0 += FMLP * WAVE) {
+					// FMLP carriers per lane at a time: their queue and table reads are in flight together
+					uint32_t e[FMLP];
+#pragma unroll
+					for (int j = 0; j < FMLP; j++) e[j] = (k0 + j * WAVE < total) ? q[k0 + j * WAVE] : 0u;
+					double xr[FMLP][K + 1];
+#pragma unroll
+					for (int j = 0; j < FMLP; j++) {
+						const double *x = tab + (size_t)(e[j] & 0x3FFFu) * KP;
+#pragma unroll
+						for (int a = 0; a <= K; a++) xr[j][a] = x[a];
+					}
+#pragma unroll
+					for (int j = 0; j < FMLP; j++) {
+						const int k = k0 + j * WAVE;
+						if (k >= total) continue;
+						const double G = sel4(r.lut, e[j] >> 14);
+						double b = 0;
+#pragma unroll
+						for (int a = 0; a < K; a++) b = fma(xr[j][a], c[a], b);
+						const double mui = xr[j][K];
+						const double adj = (G - b) * inv;
+						lst[run + k] = make_double2(adj, mui);
+						a12[0] = fma(mui, G, a12[0]);
+						a12[1] += b;
+						if (adj > 0) a12[2] += adj; else a12[3] += adj;
+						a12[4] = fma(adj, mui, a12[4]);
+						a12[5] = fma(adj * adj, mui * (1 - mui), a12[5]);
+					}
+				}
+				__builtin_amdgcn_wave_barrier();   // queue reads above stay before the next sub-step's writes
+				run += total;
+			}
+#pragma unroll
+			for (int a = 0; a < SPA3_NSEGP; a++) a12[a] = wave_sum(a12[a]);
+			if (lane == 0) {
+#pragma unroll
+				for (int a = 0; a < SPA3_NSEGP; a++) segpart[(size_t)it * SPA3_NSEGP + a] = a12[a];
+			}
 		}
-		block_sum<SPA3_NSEGP, BLOCK>(a12, sh);
-		if (tid < SPA3_NSEGP) segpart[(size_t)it * SPA3_NSEGP + tid] = a12[tid];
 	}
 }
 

@@ -87,6 +87,7 @@ struct sgx_handle {
 	int spa_levels = 12;
 	unsigned long long arena_limit = 0;   // test hook: pretend the arena is this small (0 = real size)
 	bool force_dense = false;         // test hook: every SPA variant takes the exact dense pass
+	bool fill_attr_set = false;       // spa3_fill's dynamic LDS size has been raised above 64 KiB
 	// exact-integer MFMA score path (kern_score_mfma.h)
 	bool mf_ok = false;
 	MfTab mf[MF_MAXG]{};              // one limb table per column group
@@ -344,7 +345,7 @@ static int ensure_recs(sgx_handle *h, size_t n)
 		if (h->segcnt) HIPCHK(hipFree(h->segcnt));
 		if (h->segpart) HIPCHK(hipFree(h->segpart));
 		h->segcnt = nullptr; h->segpart = nullptr;
-		h->nseg = (h->md.N + SPA3_SEG - 1) / SPA3_SEG;
+		h->nseg = (h->md.N + spa3_seg(h->md.K) - 1) / spa3_seg(h->md.K);
 		HIPCHK(hipMalloc((void **)&h->segcnt, n * (size_t)h->nseg * sizeof(int)));
 		HIPCHK(hipMalloc((void **)&h->segpart, n * (size_t)h->nseg * SPA3_NSEGP * sizeof(double)));
 		h->fb_spa2 = nullptr; h->heads = nullptr; h->chunks = nullptr; h->partial = nullptr;
@@ -457,14 +458,24 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			const dim3 gchunk((unsigned)(h->n_cu * 8));                                      \
 			const dim3 gitem((unsigned)(h->n_cu * 16));                                      \
 			hipLaunchKernelGGL(spa3_count, gitem, dim3(256), 0, st, (const uint8_t *)rows,   \
-				row_bytes, md.N, h->nseg, h->recs, h->counters, h->segcnt);                  \
+				row_bytes, md.N, h->nseg, spa3_seg(KK), h->recs, h->counters, h->segcnt);    \
 			hipLaunchKernelGGL((spa3_plan<KK>), g256, dim3(256), 0, st, md, h->nseg, h->recs,\
 				h->counters, h->cursor,                                                      \
 				(h->arena_limit ? std::min(h->arena_limit, h->arena_cap) : h->arena_cap),    \
 				h->segcnt, h->heads, h->fb_spa2, out8);      \
-			hipLaunchKernelGGL((spa3_fill<KK>), gitem, dim3(256), 0, st,                     \
-				(const uint8_t *)rows, row_bytes, md, h->nseg, h->recs, h->counters,         \
-				h->segcnt, h->heads, h->arena, h->segpart);                                  \
+			{                                                                                \
+				const size_t fl = (size_t)spa3_seg(KK) * (((KK) + 2) & ~1) * 8 + SPA3_FILL_WAVES * 1024 * 2; \
+				const int nslice = std::max(1, (2 * h->n_cu + h->nseg - 1) / h->nseg);       \
+				if (!h->fill_attr_set) {                                                     \
+					HIPCHK(hipFuncSetAttribute((const void *)spa3_fill<KK>,                  \
+						hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));               \
+					h->fill_attr_set = true;                                                 \
+				}                                                                            \
+				hipLaunchKernelGGL((spa3_fill<KK>), dim3((unsigned)std::min(h->nseg * nslice, 4 * h->n_cu)), \
+					dim3(WAVE * SPA3_FILL_WAVES), fl, st,                                    \
+					(const uint8_t *)rows, row_bytes, md, h->nseg, nslice, h->recs,          \
+					h->counters, h->segcnt, h->heads, h->arena, h->segpart);                 \
+			}                                                                                \
 			hipLaunchKernelGGL((spa3_head<KK>), g256, dim3(256), 0, st, md, h->nseg,         \
 				h->recs, h->counters, h->segpart, h->heads, h->chunks, h->chunk_cap,         \
 				h->fallback, h->fb_spa2, out8, h->force_dense ? 1 : 0);                                              \
