@@ -398,12 +398,13 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		HIPCHK(hipMemsetAsync(h->mf_acc, 0, M * (size_t)ep.acc_stride * sizeof(int), st));
 		int tps = 0;
 		const dim3 mgrid = mf_grid(h->n_cu, M, h->mf[0].ntile, &tps);
-		const bool wide = row_bytes % 128 == 0 && (size_t)h->mf[0].ntile * 64 <= row_bytes;   // else 16 B per row and tile
+		// wide rows where the registers allow it (4 value fragments + two row pieces would spill)
+		const bool wide = row_bytes % 128 == 0 && (size_t)h->mf[0].ntile * 64 <= row_bytes;
 		for (int g = 0; g < ep.ngroups; g++) {
 			const size_t lds = (size_t)2 * 16 * ep.gncol[g] * 16;
 			int *acc = h->mf_acc + ep.goff[g];
 #define MFRUN(NB, B1)                                                                          \
-	do { if (wide) hipLaunchKernelGGL((score_mfma_kernel<NB, B1, true>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
+	do { if (wide && NB <= 3) hipLaunchKernelGGL((score_mfma_kernel<NB, B1, true>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
 			(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride);      \
 		else hipLaunchKernelGGL((score_mfma_kernel<NB, B1, false>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
 			(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride); } while (0)
