@@ -136,6 +136,17 @@ int sgx_scan_u8(sgx_handle *h, const uint8_t *dosage, size_t n_variants,
 int sgx_scan_f64(sgx_handle *h, const double *dosage, size_t n_variants,
 	double *out8, uint8_t *valid);
 
+/* Aggregate tests: n_rows burden rows from 2-bit genotypes in HOST memory, then the
+ * single-variant test on every row (replaces ds_mat_burden + single_test_bin/quant inside
+ * saige_burden_test_*, saige_acatv_test_bin and saige_acato_test_bin, src/saige_main.cpp:526-976).
+ * Row r = sum over its entries e in [row_ptr[r], row_ptr[r+1]) of lut[4e + code], code = the 2-bit
+ * genotype of variant var_idx[e] (row of `packed`); the caller folds weight, mean imputation and
+ * the flip to the minor allele into lut (see saigegds_amd/aggregate.py).  out8 / valid as above,
+ * one row per burden row.  Synchronous. */
+int sgx_burden_2bit(sgx_handle *h, const uint8_t *packed, size_t bytes_per_variant,
+	size_t n_variants, size_t n_rows, const int64_t *row_ptr, const int32_t *var_idx,
+	const double *lut, double *out8, uint8_t *valid);
+
 /* Tuning / test hooks: "spa_levels" (Newton levels run in lock step before
  * stragglers go to the per-workgroup kernel), "arena_limit" (carriers; 0 = all),
  * "score_v1" (gather kernel instead of the MFMA path), "force_dense" (exact

@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libsaigehip.so")
 
 EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
-    "sgx_set_thresholds", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64",
+    "sgx_set_thresholds", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64", "sgx_burden_2bit",
     "sgx_sync", "sgx_get_stats", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
     "sgx_grm_init", "sgx_grm_init_dev", "sgx_grm_crossprod_dev", "sgx_grm_sync", "sgx_grm_free", "sgx_grm_diag", "sgx_grm_crossprod", "sgx_grm_pcg",
 )
@@ -103,6 +103,8 @@ def load():
     L.sgx_scan_u8.argtypes = [vp, vp, sz, vp, vp]
     L.sgx_scan_f64.restype = C.c_int
     L.sgx_scan_f64.argtypes = [vp, vp, sz, vp, vp]
+    L.sgx_burden_2bit.restype = C.c_int
+    L.sgx_burden_2bit.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp, vp, vp]
     L.sgx_set_option.restype = C.c_int
     L.sgx_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
     L.sgx_sync.restype = C.c_int
@@ -210,6 +212,22 @@ class Scanner:
         out, valid = self._out(dosage.shape[0])
         check(self._L.sgx_scan_f64(self._h, dosage.ctypes.data, dosage.shape[0], out.ctypes.data,
                                    valid.ctypes.data))
+        return out, valid
+
+    def burden_2bit(self, packed: np.ndarray, row_ptr, var_idx, lut):
+        """Burden rows (CSR over the rows of ``packed``, one 4-entry table per entry), then the
+        single-variant test on each row (``sgx_burden_2bit``)."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        row_ptr = np.ascontiguousarray(row_ptr, dtype=np.int64)
+        var_idx = np.ascontiguousarray(var_idx, dtype=np.int32)
+        lut = np.ascontiguousarray(lut, dtype=np.float64)
+        n_rows = row_ptr.size - 1
+        if packed.ndim != 2 or lut.shape != (var_idx.size, 4) or n_rows < 0 or (n_rows >= 0 and row_ptr[-1] != var_idx.size):
+            raise ValueError("burden_2bit: inconsistent CSR / table shapes")
+        out, valid = self._out(n_rows)
+        check(self._L.sgx_burden_2bit(self._h, packed.ctypes.data, packed.shape[1], packed.shape[0], n_rows,
+                                      row_ptr.ctypes.data, var_idx.ctypes.data, lut.ctypes.data,
+                                      out.ctypes.data, valid.ctypes.data))
         return out, valid
 
     # -- device-resident scans (pointers are raw device addresses) ---------

@@ -65,6 +65,7 @@ static int fail(int code, const char *fmt, ...)
 #include "kern_spa3.h"
 #include "kern_synth.h"
 #include "kern_grm.h"
+#include "kern_burden.h"
 
 // ---------------------------------------------------------------------------
 // host side
@@ -101,6 +102,7 @@ struct sgx_handle {
 	double *scratch = nullptr; size_t scratch_stride = 0; int spa_grid = 0;
 	// host-pointer staging
 	uint8_t *stage_in = nullptr; size_t stage_in_cap = 0;
+	uint8_t *stage_pk = nullptr; size_t stage_pk_cap = 0;   // burden: packed rows, CSR and tables
 	double *stage_out = nullptr; uint8_t *stage_valid = nullptr; size_t stage_out_cap = 0;
 	hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 	sgx_stats stats{};
@@ -321,7 +323,7 @@ extern "C" void sgx_free(sgx_handle *h)
 	(void)hipFree(h->arena); (void)hipFree(h->cursor); (void)hipFree(h->segcnt); (void)hipFree(h->segpart); (void)hipFree(h->chunks); (void)hipFree(h->partial);
 	(void)hipFree(h->dFl); (void)hipFree(h->mf_acc);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
-	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid);
+	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid); (void)hipFree(h->stage_pk);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
 	for (int i = 0; i < 3; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -661,6 +663,81 @@ extern "C" int sgx_scan_f64(sgx_handle *h, const double *dosage, size_t M, doubl
 {
 	const size_t rb = h ? (size_t)h->md.N * sizeof(double) : 0;
 	return scan_host<IN_F64>(h, dosage, rb, rb, M, out8, valid);
+}
+
+// Burden rows from 2-bit genotypes, then the single-variant test on each row
+// (saige_burden_test_bin/quant and the burden halves of ACAT-V / ACAT-O, saige_main.cpp:615-976)
+extern "C" int sgx_burden_2bit(sgx_handle *h, const uint8_t *packed, size_t bpv, size_t n_variants,
+	size_t n_rows, const int64_t *row_ptr, const int32_t *var_idx, const double *lut,
+	double *out8, uint8_t *valid)
+{
+	if (!h) return fail(SGX_EINVAL, "sgx_burden_2bit: NULL handle");
+	if (n_rows == 0) return SGX_OK;
+	if (!packed || !row_ptr || !var_idx || !lut || !out8 || !valid)
+		return fail(SGX_EINVAL, "sgx_burden_2bit: NULL buffer");
+	const int N = h->md.N;
+	if (bpv < (size_t)(N + 3) / 4)
+		return fail(SGX_EINVAL, "Invalid length of dosages: bytes_per_variant=%zu < ceil(N/4)=%zu", bpv, (size_t)(N + 3) / 4);
+	const int64_t nnz = row_ptr[n_rows];
+	if (row_ptr[0] != 0 || nnz < 0) return fail(SGX_EINVAL, "sgx_burden_2bit: bad row_ptr");
+	for (size_t r = 0; r < n_rows; r++)
+		if (row_ptr[r + 1] < row_ptr[r]) return fail(SGX_EINVAL, "sgx_burden_2bit: row_ptr not ascending");
+	for (int64_t e = 0; e < nnz; e++)
+		if (var_idx[e] < 0 || (size_t)var_idx[e] >= n_variants)
+			return fail(SGX_EINVAL, "sgx_burden_2bit: variant index %d out of range", var_idx[e]);
+	int rc = set_dev(h);
+	if (rc) return rc;
+	// device copies: packed rows (4-byte aligned stride), CSR, tables
+	const size_t dbpv = ((size_t)(N + 15) / 16) * 4;
+	const size_t o_ptr = (n_variants * dbpv + 15) & ~(size_t)15;
+	const size_t o_idx = (o_ptr + (n_rows + 1) * sizeof(long long) + 15) & ~(size_t)15;
+	const size_t o_lut = (o_idx + (size_t)std::max<int64_t>(nnz, 1) * sizeof(int) + 15) & ~(size_t)15;
+	const size_t need = o_lut + (size_t)std::max<int64_t>(nnz, 1) * 4 * sizeof(double);
+	if (need > h->stage_pk_cap) {
+		HIPCHK(hipStreamSynchronize(h->stream));
+		if (h->stage_pk) HIPCHK(hipFree(h->stage_pk));
+		h->stage_pk = nullptr; h->stage_pk_cap = 0;
+		HIPCHK(hipMalloc((void **)&h->stage_pk, need));
+		h->stage_pk_cap = need;
+	}
+	HIPCHK(hipMemsetAsync(h->stage_pk, 0, n_variants * dbpv, h->stream));
+	HIPCHK(hipMemcpy2DAsync(h->stage_pk, dbpv, packed, bpv, std::min(bpv, dbpv), n_variants, hipMemcpyHostToDevice, h->stream));
+	std::vector<long long> rp(row_ptr, row_ptr + n_rows + 1);
+	HIPCHK(hipMemcpyAsync(h->stage_pk + o_ptr, rp.data(), rp.size() * sizeof(long long), hipMemcpyHostToDevice, h->stream));
+	if (nnz > 0) {
+		HIPCHK(hipMemcpyAsync(h->stage_pk + o_idx, var_idx, (size_t)nnz * sizeof(int), hipMemcpyHostToDevice, h->stream));
+		HIPCHK(hipMemcpyAsync(h->stage_pk + o_lut, lut, (size_t)nnz * 4 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+	}
+	HIPCHK(hipStreamSynchronize(h->stream));      // rp is a local
+	const size_t row_bytes = (size_t)N * sizeof(double);
+	size_t chunk = std::max<size_t>(1, STAGE_BYTES / row_bytes);
+	chunk = std::min(chunk, n_rows);
+	rc = ensure_stage(h, chunk * row_bytes, chunk);
+	if (rc) return rc;
+	rc = ensure_recs(h, chunk);
+	if (rc) return rc;
+	sgx_stats total{};
+	const int ndw = (N + 15) >> 4;
+	for (size_t off = 0; off < n_rows; off += chunk) {
+		const size_t m = std::min(chunk, n_rows - off);
+		hipLaunchKernelGGL(burden_collapse_kernel, dim3((unsigned)((ndw + 255) / 256), (unsigned)m), dim3(256), 0, h->stream,
+			h->stage_pk, dbpv, N, reinterpret_cast<const long long *>(h->stage_pk + o_ptr) + off,
+			reinterpret_cast<const int *>(h->stage_pk + o_idx), reinterpret_cast<const double *>(h->stage_pk + o_lut),
+			reinterpret_cast<double *>(h->stage_in), (size_t)N);
+		HIPCHK(hipGetLastError());
+		rc = launch_scan<IN_F64>(h, h->stage_in, row_bytes, m, h->stage_out, h->stage_valid);
+		if (rc) return rc;
+		HIPCHK(hipMemcpyAsync(out8 + off * 8, h->stage_out, m * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(valid + off, h->stage_valid, m, hipMemcpyDeviceToHost, h->stream));
+		rc = sgx_sync(h);
+		if (rc) return rc;
+		total.n_variants += h->stats.n_variants; total.n_valid += h->stats.n_valid;
+		total.n_spa += h->stats.n_spa; total.n_spa_dense += h->stats.n_spa_dense; total.n_spa_slow += h->stats.n_spa_slow;
+		total.ms_score += h->stats.ms_score; total.ms_spa += h->stats.ms_spa; total.ms_total += h->stats.ms_total;
+		total.score_launches += h->stats.score_launches; total.spa_launches += h->stats.spa_launches;
+	}
+	h->stats = total;
+	return SGX_OK;
 }
 
 extern "C" int sgx_synth_2bit_dev(sgx_handle *h, uint8_t *packed_dev, size_t bpv, int32_t n_samp,
