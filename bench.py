@@ -64,11 +64,19 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (no CPU fallback)")
+    # rehearsal on a one-GPU box: SGX_BENCH_REHEARSE=1 puts every rank on device 0 and moves the
+    # exchange to gloo (RCCL refuses two ranks on one device); the driver's runs never set it
+    rehearse = os.environ.get("SGX_BENCH_REHEARSE", "") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     wl = dict(WORKLOADS[args.workload])
     if args.n_samp:
@@ -121,12 +129,14 @@ def main():
         # the path's one exchange step: result table to rank 0
         used = sorted({(warmup + i) % pool for i in range(steps)})
         tab = out[used].reshape(-1, 8)
+        if rehearse:
+            tab = tab.cpu()
         gathered = [torch.empty_like(tab) for _ in range(world)] if rank == 0 else None
         dist.gather(tab, gathered, dst=0)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
