@@ -76,6 +76,8 @@ struct MfEpi {
 	int col_ones;              // group 0: column of the constant 1
 	int col_b1;                // group 0: first column of the w limbs in the bit-1 fragment
 	unsigned char cgrp[MF_MAXP], ccol[MF_MAXP], climb[MF_MAXP];   // per value column: group, first limb column, limbs
+	int derive_c;              // quantitative traits: c' = XVXi e instead of carried columns (climb = 0)
+	double XVXi[SGX_MAX_COEFF * SGX_MAX_COEFF];
 	int escale[MF_MAXP];       // F = q * 2^-escale
 	long long ftot_hi[MF_MAXP];// sum_i q[i,c] = hi * 2^32 + lo
 	long long ftot_lo[MF_MAXP];
@@ -322,7 +324,7 @@ score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf
 	const int N = md.N;
 	const int n3 = am0[ep.col_ones];
 	const long long AC = (long long)a0[ep.col_ones] - 3ll * n3;
-	const int n2 = a0[ep.col_b1 + MF_NLIMB] / 2 - n3;      // bit-1 plane (0/2) against the ones column
+	const int n2 = a0[ep.col_b1 + ep.climb[CW]] / 2 - n3;  // bit-1 plane (0/2) against the ones column
 	const int n1 = (int)(AC - 2ll * n2);
 	const VarHead h = make_head(md, (double)AC, N - n3);
 	double *o = out8 + (size_t)j * 8;
@@ -333,6 +335,7 @@ score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf
 #pragma unroll
 	for (int c = 0; c < P; c++) {
 		const int g = ep.cgrp[c], cc = ep.ccol[c], nl = ep.climb[c];
+		if (nl == 0) { acc[c] = 0; continue; }            // derived below
 		const int *a = a0 + ep.goff[g];
 		const HiLo V = mf_limbs(a + cc, nl);
 		const HiLo T3 = mf_limbs(a + ep.gncol[g] + cc, nl);
@@ -345,7 +348,7 @@ score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf
 		if (c == CW) { Wm = W; T3m = T3; }
 	}
 	{
-		const HiLo B2 = mf_limbs(a0 + ep.col_b1);         // = 2 (T2 + T3), the plane holds 0/2
+		const HiLo B2 = mf_limbs(a0 + ep.col_b1, ep.climb[CW]);   // = 2 (T2 + T3), the plane holds 0/2
 		const HiLo H2 = hl(B2.hi / 2 - T3m.hi, B2.lo / 2 - T3m.lo);   // every limb sum of that plane is even
 		const double t3d = hl_to_double(T3m);
 		double w;
@@ -358,6 +361,15 @@ score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf
 			w = hl_to_double(hl_axpy(4, R, S1)) + (2 - imp) * (2 - imp) * t3d;
 		}
 		acc[CW] = ldexp(w, -ep.escale[CW]);
+	}
+	if (ep.derive_c) {
+#pragma unroll
+		for (int x = 0; x < K; x++) {
+			double cx = 0;
+#pragma unroll
+			for (int y = 0; y < K; y++) cx = fma(ep.XVXi[x * K + y], acc[K + y], cx);
+			acc[x] = cx;
+		}
 	}
 	double cbuf[KMAX], pn, Ssc, v2sc;
 	valid[j] = 1;

@@ -153,6 +153,74 @@ static int dev_upload(T **dst, const std::vector<T> &src)
 	return SGX_OK;
 }
 
+// XVXi with  t_XVX_inv_XV[i,:] = X[i,:] XVXi  for a quantitative model (weights 1; reference
+// R/assoc_single.r:33-41 builds t_XVX_inv_XV from the same inverse).  Start from the inverse of
+// XVX = X'X, then correct it by the least-squares residual against the model's own matrix, so that
+// c' = XVXi e matches the reference's sum_i G_i t_XVX_inv_XV[i,:] to rounding even when X'X is badly
+// conditioned.  False (-> the c' columns are carried as for binary traits) if the model's matrix is
+// not such an image.
+static bool fit_xvx_inverse(const sgx_model *m, double *out)
+{
+	const int N = m->n_samp, K = m->n_coeff;
+	typedef long double LD;
+	auto invert = [&](std::vector<LD> a, std::vector<LD> &inv) -> bool {   // Gauss-Jordan, partial pivoting
+		inv.assign((size_t)K * K, 0);
+		for (int i = 0; i < K; i++) inv[(size_t)i * K + i] = 1;
+		for (int c = 0; c < K; c++) {
+			int pv = c;
+			for (int r = c + 1; r < K; r++) if (fabsl(a[(size_t)r * K + c]) > fabsl(a[(size_t)pv * K + c])) pv = r;
+			if (!(fabsl(a[(size_t)pv * K + c]) > 0)) return false;
+			for (int x = 0; x < K; x++) { std::swap(a[(size_t)c * K + x], a[(size_t)pv * K + x]); std::swap(inv[(size_t)c * K + x], inv[(size_t)pv * K + x]); }
+			const LD d = 1 / a[(size_t)c * K + c];
+			for (int x = 0; x < K; x++) { a[(size_t)c * K + x] *= d; inv[(size_t)c * K + x] *= d; }
+			for (int r = 0; r < K; r++) if (r != c) {
+				const LD f = a[(size_t)r * K + c];
+				if (f == 0) continue;
+				for (int x = 0; x < K; x++) { a[(size_t)r * K + x] -= f * a[(size_t)c * K + x]; inv[(size_t)r * K + x] -= f * inv[(size_t)c * K + x]; }
+			}
+		}
+		return true;
+	};
+	std::vector<LD> A((size_t)K * K), M0, G((size_t)K * K, 0), Gi, B((size_t)K * K, 0), M((size_t)K * K);
+	for (int a = 0; a < K * K; a++) A[a] = m->XVX[a];
+	if (!invert(A, M0)) return false;
+	for (int i = 0; i < N; i++) {        // R = t_XVX_inv_XV - X M0;  G = X'X;  B = X'R
+		const double *x = m->t_X + (size_t)i * K;
+		LD r[SGX_MAX_COEFF];
+		for (int k = 0; k < K; k++) {
+			LD t = m->t_XVX_inv_XV[(size_t)i * K + k];
+			for (int b = 0; b < K; b++) t -= (LD)x[b] * M0[(size_t)b * K + k];
+			r[k] = t;
+		}
+		for (int a = 0; a < K; a++)
+			for (int b = 0; b < K; b++) { G[(size_t)a * K + b] += (LD)x[a] * x[b]; B[(size_t)a * K + b] += (LD)x[a] * r[b]; }
+	}
+	if (!invert(G, Gi)) return false;
+	for (int a = 0; a < K; a++)
+		for (int b = 0; b < K; b++) {
+			LD d = 0;
+			for (int x = 0; x < K; x++) d += Gi[(size_t)a * K + x] * B[(size_t)x * K + b];
+			M[(size_t)a * K + b] = M0[(size_t)a * K + b] + d;
+		}
+	// the fit must reproduce the model's matrix to rounding
+	LD worst = 0, scale = 0;
+	for (int i = 0; i < N; i++) {
+		const double *x = m->t_X + (size_t)i * K;
+		for (int k = 0; k < K; k++) {
+			LD t = 0;
+			for (int b = 0; b < K; b++) t += (LD)x[b] * M[(size_t)b * K + k];
+			worst = std::max(worst, fabsl(t - (LD)m->t_XVX_inv_XV[(size_t)i * K + k]));
+			scale = std::max(scale, fabsl((LD)m->t_XVX_inv_XV[(size_t)i * K + k]));
+		}
+	}
+	if (!(worst <= 1e-13L * scale)) return false;
+	// c'_x = sum_y XVXi[x*K + y] e_y  with  c' = M' e
+	for (int a = 0; a < K; a++)
+		for (int b = 0; b < K; b++) out[(size_t)b * K + a] = (double)M[(size_t)a * K + b];
+	for (int a = 0; a < K * K; a++) if (!std::isfinite(out[a])) return false;
+	return true;
+}
+
 extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 {
 	if (!m || !out) return fail(SGX_EINVAL, "sgx_init: NULL argument");
@@ -207,12 +275,19 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		const int ntile = 2 * ((ngrp + 31) / 32);   // even: the wide-row kernel walks pairs of tiles
 		const size_t ngrp_pad = (size_t)ntile * 16;
 		// pack the columns: s, w and the constant 1 first (group 0), then e, then c'
+		// Quantitative traits: the weights are 1 (saige_main.cpp:227-228), so w is the constant-1
+		// column (one limb) and t_XVX_inv_XV = X (X'X)^-1 makes c' a K x K image of e = sum G X:
+		// the c' columns are not carried, the epilogue forms c' = XVXi e (XVXi fitted to the model's
+		// own t_XVX_inv_XV, fit_xvx_inverse).  Binary traits keep them: there the two weight vectors
+		// (no-K V in t_XVX_inv_XV, GLMM mu2 in e) differ.
+		ep.derive_c = quant && fit_xvx_inverse(m, ep.XVXi) ? 1 : 0;
 		std::vector<int> order = {CS, CW};
 		for (int k = 0; k < K; k++) order.push_back(K + k);
-		for (int k = 0; k < K; k++) order.push_back(k);
+		if (!ep.derive_c) for (int k = 0; k < K; k++) order.push_back(k);
+		for (int k = 0; k < K; k++) { ep.cgrp[k] = 0; ep.ccol[k] = 0; ep.climb[k] = 0; }
 		int g = 0, used = 1, glimbs[MF_MAXG] = {0};   // group 0: one column for the constant 1
 		for (int c : order) {
-			const int nl = c >= 2 * K ? MF_NLIMB : (c >= K ? MF_LIMB_E : MF_LIMB_A);
+			const int nl = c == CW ? (quant ? 1 : MF_NLIMB) : c >= 2 * K ? MF_NLIMB : (c >= K ? MF_LIMB_E : MF_LIMB_A);
 			if (used + nl > MF_GLIMBS) { glimbs[g] = used; g++; used = 0; }
 			ep.cgrp[c] = (unsigned char)g; ep.ccol[c] = (unsigned char)(used - (g == 0 ? 1 : 0)); ep.climb[c] = (unsigned char)nl;
 			used += nl;
@@ -240,11 +315,12 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		};
 		for (int c = 0; c < P; c++) {
 			const int gg = ep.cgrp[c], cc = ep.ccol[c], nl = ep.climb[c];
+			if (nl == 0) { ep.escale[c] = 0; ep.ftot_hi[c] = ep.ftot_lo[c] = 0; continue; }   // derived column
 			double mx = 0;
 			for (int i = 0; i < N; i++) mx = std::max(mx, std::fabs(F[(size_t)i * P + c]));
 			int ex = 0;
 			if (mx > 0) (void)std::frexp(mx, &ex);
-			ep.escale[c] = 8 * nl - 2 - ex;
+			ep.escale[c] = (quant && c == CW) ? 0 : 8 * nl - 2 - ex;   // quantitative w = 1 exactly: q = 1
 			__int128 tot = 0;
 			for (int i = 0; i < N; i++) {
 				long long q = std::llrint(std::ldexp(F[(size_t)i * P + c], ep.escale[c]));
@@ -264,7 +340,7 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		}
 		for (int i = 0; i < N; i++) {
 			at(0, i, ep.col_ones) = 1;
-			at(0, i, ep.col_b1 + MF_NLIMB) = 1;
+			at(0, i, ep.col_b1 + ep.climb[CW]) = 1;
 		}
 		h->mf_ok = true;
 	}
