@@ -165,6 +165,24 @@ class Oracle:
         return out, valid
 
 
+class OracleScanner(Oracle):
+    """The scan oracle behind the interface of ``saigegds_amd._lib.Scanner`` that the aggregate
+    driver uses (tests of its host logic without a GPU): ``burden_2bit`` collapses in numpy the
+    way ``burden_collapse_kernel`` does and hands the rows to ``scan_f64``."""
+
+    def burden_2bit(self, packed, row_ptr, var_idx, lut):
+        from saigegds_amd.gds import unpack_dosage_2bit
+        codes = unpack_dosage_2bit(np.ascontiguousarray(packed, dtype=np.uint8), self.n)
+        rows = np.zeros((len(row_ptr) - 1, self.n))
+        for r in range(len(row_ptr) - 1):
+            for e in range(int(row_ptr[r]), int(row_ptr[r + 1])):
+                rows[r] += np.asarray(lut[e])[codes[var_idx[e]]]
+        return self.scan_f64(rows)
+
+    def close(self):
+        Oracle.close(self)
+
+
 class GrmOracle:
     """Implicit GRM of the null-model fit, CPU restatement (grm_oracle.c)."""
 

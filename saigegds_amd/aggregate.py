@@ -128,7 +128,7 @@ class _Prepared:
     pass
 
 
-def _prepare(gdsfile, modobj, units, wbeta, spa_pval, var_ratio, verbose, what) -> _Prepared:
+def _prepare(gdsfile, modobj, units, wbeta, spa_pval, var_ratio, verbose, what, scanner_factory=None) -> _Prepared:
     """Common head of the three drivers (R/assoc_aggregate.r:55-150): checks, sample matching,
     model, and the per-variant scan of every variant that occurs in a unit."""
     if verbose:
@@ -181,7 +181,7 @@ def _prepare(gdsfile, modobj, units, wbeta, spa_pval, var_ratio, verbose, what) 
     pr.sm = init_nullmod(mod, ii, 0.0, 0.0, 1.0, spa_pval, var_ratio)
     pr.binary = mod.trait_type == "binary"
     pr.wb_colnm = [f"b{a:g}_{b:g}" for a, b in pr.wbeta.T]
-    pr.sc = Scanner(pr.sm)
+    pr.sc = Scanner(pr.sm) if scanner_factory is None else scanner_factory(pr.sm)   # tests inject the CPU oracle
     if verbose:
         print("Calculating p-values:")
     out, valid = pr.sc.scan_2bit(packed)
@@ -261,11 +261,11 @@ def _row_result(o, ok, n_snp, summac_thr):
 def seqAssocGLMM_spaBurden(gdsfile, modobj, units, wbeta=AggrParamBeta, summac: float = 3, dsnode: str = "",
                            spa_pval: float = 0.05, var_ratio: float = float("nan"), res_savefn: str = "",
                            res_compress: str = "LZMA", parallel=False, verbose: bool = True,
-                           verbose_maf: bool = True) -> Dict[str, Any]:
+                           verbose_maf: bool = True, scanner_factory=None) -> Dict[str, Any]:
     """Burden tests per unit and weight set (R/assoc_aggregate.r:51-302)."""
     if not (_is_num(summac) and math.isfinite(summac)):
         raise TypeError("is.finite(summac) is not TRUE")
-    pr = _prepare(gdsfile, modobj, units, wbeta, spa_pval, var_ratio, verbose, "SAIGE burden analysis:")
+    pr = _prepare(gdsfile, modobj, units, wbeta, spa_pval, var_ratio, verbose, "SAIGE burden analysis:", scanner_factory)
     try:
         ans = _summary_cols(pr)
         sets = [[_dbeta(pr.maf[r], a, b) for a, b in pr.wbeta.T] for r in pr.rows]
@@ -323,9 +323,9 @@ def _acatv(pr: _Prepared, burden_mac: float, burden_summac: float):
 def seqAssocGLMM_spaACAT_V(gdsfile, modobj, units, wbeta=AggrParamBeta, burden_mac: float = 10,
                            burden_summac: float = 3, dsnode: str = "", spa_pval: float = 0.05,
                            var_ratio: float = float("nan"), res_savefn: str = "", res_compress: str = "LZMA",
-                           parallel=False, verbose: bool = True, verbose_maf: bool = True) -> Dict[str, Any]:
+                           parallel=False, verbose: bool = True, verbose_maf: bool = True, scanner_factory=None) -> Dict[str, Any]:
     """ACAT-V tests (R/assoc_aggregate.r:309-557); binary outcomes only, as in the reference."""
-    pr = _prepare(gdsfile, modobj, units, wbeta, spa_pval, var_ratio, verbose, "SAIGE ACAT-V analysis:")
+    pr = _prepare(gdsfile, modobj, units, wbeta, spa_pval, var_ratio, verbose, "SAIGE ACAT-V analysis:", scanner_factory)
     try:
         if not pr.binary:
             raise NotImplementedError("'saige_acatv_test_quant' not implemented.")
@@ -345,10 +345,10 @@ def seqAssocGLMM_spaACAT_V(gdsfile, modobj, units, wbeta=AggrParamBeta, burden_m
 def seqAssocGLMM_spaACAT_O(gdsfile, modobj, units, wbeta=AggrParamBeta, burden_mac: float = 10,
                            burden_summac: float = 3, dsnode: str = "", spa_pval: float = 0.05,
                            var_ratio: float = float("nan"), res_savefn: str = "", res_compress: str = "LZMA",
-                           parallel=False, verbose: bool = True, verbose_maf: bool = True) -> Dict[str, Any]:
+                           parallel=False, verbose: bool = True, verbose_maf: bool = True, scanner_factory=None) -> Dict[str, Any]:
     """ACAT-O: burden and ACAT-V p-values of every weight set combined by ACAT
     (R/assoc_aggregate.r:564-797, saige_acato_test_bin src/saige_main.cpp:845-976)."""
-    pr = _prepare(gdsfile, modobj, units, wbeta, spa_pval, var_ratio, verbose, "SAIGE ACAT-O analysis:")
+    pr = _prepare(gdsfile, modobj, units, wbeta, spa_pval, var_ratio, verbose, "SAIGE ACAT-O analysis:", scanner_factory)
     try:
         if not pr.binary:
             raise NotImplementedError("'saige_acato_test_quant' not implemented.")

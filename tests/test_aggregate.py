@@ -49,9 +49,10 @@ def test_acat_oracle_agrees_with_driver_combination():
         assert acat_pval(p, w) == pytest.approx(oacat(list(p), list(w)), rel=1e-14)
 
 
-@pytest.mark.gpu
-def test_aggregate_tests_match_cpu_restatement():
-    import torch  # noqa: F401
+@pytest.mark.parametrize("device", [pytest.param("gpu", marks=pytest.mark.gpu), "oracle"])
+def test_aggregate_tests_match_cpu_restatement(device):
+    """device = gpu: the product path; device = oracle: the driver's host logic (batching, CSR,
+    tables, weights, combination) with the scan oracle in place of the library (no GPU)."""
     from oracle.aggregate_oracle import acato_unit, acatv_unit, burden_unit
     from oracle.oracle import Oracle
     from saigegds_amd.aggregate import (AggrParamBeta, seqAssocGLMM_spaACAT_O, seqAssocGLMM_spaACAT_V,
@@ -63,12 +64,18 @@ def test_aggregate_tests_match_cpu_restatement():
     m = np.load(os.path.join(GOLD, "saige_model.npz"))
     mod = NullModel(trait_type="binary", tau=m["tau"], fitted_values=m["fitted_values"], sample_id=list(m["sample_id"]),
                     var_ratio=m["var_ratio"], y=m["y"], V=m["V"], X1=m["X1"], XV=m["XV"], XXVX_inv=m["XXVX_inv"])
-    nv = 1500
+    nv = 1500 if device == "gpu" else 500
     src = GenotypeSource(list(g["sample_id"]), packed=g["packed"][:nv], variant_id=g["variant_id"][:nv])
     units = _sliding_units(nv)
-    b = seqAssocGLMM_spaBurden(src, mod, units, verbose=False)
-    v = seqAssocGLMM_spaACAT_V(src, mod, units, verbose=False)
-    o = seqAssocGLMM_spaACAT_O(src, mod, units, verbose=False)
+    kw = {}
+    if device == "gpu":
+        import torch  # noqa: F401
+    else:
+        from oracle.oracle import OracleScanner
+        kw["scanner_factory"] = OracleScanner
+    b = seqAssocGLMM_spaBurden(src, mod, units, verbose=False, **kw)
+    v = seqAssocGLMM_spaACAT_V(src, mod, units, verbose=False, **kw)
+    o = seqAssocGLMM_spaACAT_O(src, mod, units, verbose=False, **kw)
     # the reference's own check (test.saige_acta_o)
     for k in ("1_1", "1_25"):
         assert np.array_equal(o["pval.b" + k], b["pval.b" + k], equal_nan=True)
@@ -86,7 +93,7 @@ def test_aggregate_tests_match_cpu_restatement():
         ok = ~np.isnan(a)
         assert np.all(np.abs(a[ok] - c[ok]) <= 1e-9 * np.abs(c[ok]) + 1e-300), what
 
-    for u in (0, 3, 7, len(units) - 1):
+    for u in sorted({0, 3, min(7, len(units) - 1), len(units) - 1}):
         ds = ds_all[units[u] - 1]
         rb = burden_unit(orc, ds, wb, 3)
         for i, k in enumerate(("b1_1", "b1_25")):
