@@ -177,3 +177,124 @@ score_ds_kernel(const T *__restrict__ ds, int M, DevModel md, SpaRec *__restrict
 		atomicAdd(&counters[1], 1);
 	}
 }
+
+
+// ---------------------------------------------------------------------------
+// Score kernels for dosage rows, tiled: one pass, the score vectors shared through LDS.
+//
+// score_ds_kernel above gathers the P score values of a sample (72 B at K = 3) once per variant
+// and sample and reads each row twice, i.e. ~10 B of F and 2 B of row per byte of input.  Here a
+// workgroup takes 32 variants and one of `nsplit` sample ranges, walks the range in tiles whose F
+// rows are staged in LDS once for all 32, and makes ONE pass by carrying, per variant and column,
+//     V = sum_valid g f     U = sum_valid (2 - g) f     T3 = sum_missing f
+// (g^2 resp. (2 - g)^2 for the last column), from which the epilogue takes the imputed sums in
+// either allele orientation without cancellation:  V + imp T3   or   U + (2 - imp) T3.
+// Partial sums go to part[split][variant][3P + 2]; score_ds_tile_epilogue adds them in split
+// order (deterministic) and finishes the row.  The sample split keeps the chip busy when a call
+// brings few rows (host-staged dosage blocks, burden rows).
+#define DS_TILE_VB 32        /* variants per workgroup */
+#define DS_TILE_LPV 8        /* lanes per variant      */
+
+template <int P, typename T>
+__global__ void __launch_bounds__(256)
+score_ds_tile_kernel(const T *__restrict__ ds, int M, DevModel md, int per_split, double *__restrict__ part)
+{
+	constexpr int BLOCK = 256, LPV = DS_TILE_LPV, VB = DS_TILE_VB, NP = 3 * P + 2;
+	constexpr int TS = ((4096 / P) & ~63) < 64 ? 64 : ((4096 / P) & ~63);   // samples per tile: <= 32 KiB of F
+	__shared__ __attribute__((aligned(16))) double ftile[TS * P];
+	const int N = md.N, tid = threadIdx.x;
+	const int vl = tid / LPV, l = tid % LPV;
+	const int j = blockIdx.x * VB + vl;
+	const bool live = j < M;
+	const T *row = ds + (size_t)(live ? j : 0) * N;
+	const int s0 = blockIdx.y * per_split, s1 = min(N, s0 + per_split);
+	double V[P], U[P], T3[P];
+#pragma unroll
+	for (int a = 0; a < P; a++) { V[a] = 0; U[a] = 0; T3[a] = 0; }
+	double sumg = 0, nvalid = 0;
+	for (int t0 = s0; t0 < s1; t0 += TS) {
+		const int ts = min(TS, s1 - t0);
+		__syncthreads();
+		{
+			const double2 *src = reinterpret_cast<const double2 *>(md.F + (size_t)t0 * P);
+			double2 *dst = reinterpret_cast<double2 *>(ftile);
+			for (int i = tid; i < ts * (P / 2); i += BLOCK) dst[i] = src[i];
+		}
+		__syncthreads();
+		if (live) {
+			for (int i = l; i < ts; i += LPV) {
+				const T v = row[t0 + i];
+				const double *f = ftile + i * P;
+				if (ds_missing<T>(v)) {
+#pragma unroll
+					for (int a = 0; a < P; a++) T3[a] += f[a];
+				} else {
+					const double g = (double)v, h2 = 2 - g;
+					sumg += g; nvalid += 1;
+#pragma unroll
+					for (int a = 0; a < P - 1; a++) { V[a] = fma(g, f[a], V[a]); U[a] = fma(h2, f[a], U[a]); }
+					V[P - 1] = fma(g * g, f[P - 1], V[P - 1]);
+					U[P - 1] = fma(h2 * h2, f[P - 1], U[P - 1]);
+				}
+			}
+		}
+	}
+	// the LPV lanes of a variant are consecutive lanes of one wave
+#pragma unroll
+	for (int o = LPV / 2; o > 0; o >>= 1) {
+		sumg += __shfl_xor(sumg, o, WAVE);
+		nvalid += __shfl_xor(nvalid, o, WAVE);
+#pragma unroll
+		for (int a = 0; a < P; a++) {
+			V[a] += __shfl_xor(V[a], o, WAVE);
+			U[a] += __shfl_xor(U[a], o, WAVE);
+			T3[a] += __shfl_xor(T3[a], o, WAVE);
+		}
+	}
+	if (!live || l != 0) return;
+	double *o = part + ((size_t)blockIdx.y * M + j) * NP;
+	o[0] = sumg; o[1] = nvalid;
+#pragma unroll
+	for (int a = 0; a < P; a++) { o[2 + a] = V[a]; o[2 + P + a] = U[a]; o[2 + 2 * P + a] = T3[a]; }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+score_ds_tile_epilogue(int M, DevModel md, int nsplit, const double *__restrict__ part,
+	SpaRec *__restrict__ recs, int *__restrict__ counters, double *__restrict__ out8, uint8_t *__restrict__ valid)
+{
+	constexpr int NP = 3 * P + 2;
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= M) return;
+	double t[NP];
+#pragma unroll
+	for (int a = 0; a < NP; a++) t[a] = 0;
+	for (int s = 0; s < nsplit; s++) {
+		const double *p = part + ((size_t)s * M + j) * NP;
+#pragma unroll
+		for (int a = 0; a < NP; a++) t[a] += p[a];
+	}
+	const VarHead h = make_head(md, t[0], (int)t[1]);
+	double *o = out8 + (size_t)j * 8;
+	if (!h.pass) { nan_row(o); valid[j] = 0; return; }
+	const double imp = h.minus ? 2 - 2 * h.AF : 2 * h.AF;       // the imputed value in the tested orientation
+	const double *V = t + 2, *U = t + 2 + P, *T3 = t + 2 + 2 * P;
+	double acc[P];
+#pragma unroll
+	for (int a = 0; a < P - 1; a++) acc[a] = (h.minus ? U[a] : V[a]) + imp * T3[a];
+	acc[P - 1] = (h.minus ? U[P - 1] : V[P - 1]) + imp * imp * T3[P - 1];
+	double cbuf[KMAX], pn, Ssc, v2sc;
+	valid[j] = 1;
+	if (score_epilogue(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
+		const int slot = atomicAdd(&counters[0], 1);
+		SpaRec r;
+		r.j = j; r.minus = h.minus; r.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
+		r.nnz = 0; r.has_gmu = 0; r.sum_gmu = 0;
+		r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc;
+		// dosage rows carry real values: lut[3] holds the imputed value, the SPA kernel re-reads the row
+		for (int a = 0; a < 4; a++) r.lut[a] = h.lut[a];
+		for (int a = 0; a < KMAX; a++) r.c[a] = (a < md.K) ? cbuf[a] : 0.0;
+		recs[slot] = r;
+	}
+	atomicAdd(&counters[1], 1);
+}

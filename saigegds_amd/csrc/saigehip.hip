@@ -103,6 +103,7 @@ struct sgx_handle {
 	// host-pointer staging
 	uint8_t *stage_in = nullptr; size_t stage_in_cap = 0;
 	uint8_t *stage_pk = nullptr; size_t stage_pk_cap = 0;   // burden: packed rows, CSR and tables
+	double *ds_part = nullptr; size_t ds_part_cap = 0;       // dosage score kernels: per-split partial sums
 	double *stage_out = nullptr; uint8_t *stage_valid = nullptr; size_t stage_out_cap = 0;
 	hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 	sgx_stats stats{};
@@ -399,7 +400,7 @@ extern "C" void sgx_free(sgx_handle *h)
 	(void)hipFree(h->arena); (void)hipFree(h->cursor); (void)hipFree(h->segcnt); (void)hipFree(h->segpart); (void)hipFree(h->chunks); (void)hipFree(h->partial);
 	(void)hipFree(h->dFl); (void)hipFree(h->mf_acc);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
-	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid); (void)hipFree(h->stage_pk);
+	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid); (void)hipFree(h->stage_pk); (void)hipFree(h->ds_part);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
 	for (int i = 0; i < 3; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -511,7 +512,31 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			if (INPUT == IN_2BIT)                                                                \
 				hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, SB>), grid, dim3(SB), 0, st,     \
 					(const uint8_t *)rows, row_bytes, (int)M, md, h->recs, h->counters, out8, valid); \
-			else if (INPUT == IN_U8)                                                             \
+			else if (KK <= 8 && !h->force_v1) {                                                  \
+				/* tiled one-pass kernels: 32 variants x a sample range per workgroup */         \
+				constexpr int PT = (KK <= 8) ? 2 * KK + 2 : 4;                                   \
+				const int vb = (int)((M + DS_TILE_VB - 1) / DS_TILE_VB);                         \
+				int ns = std::max(1, std::min((4 * h->n_cu + vb - 1) / vb, (md.N + 4095) / 4096)); \
+				int per = (((md.N + ns - 1) / ns) + 63) & ~63;                                   \
+				ns = (md.N + per - 1) / per;                                                     \
+				const size_t need = (size_t)ns * M * (3 * PT + 2) * sizeof(double);              \
+				if (need > h->ds_part_cap) {                                                     \
+					HIPCHK(hipStreamSynchronize(st));                                            \
+					if (h->ds_part) HIPCHK(hipFree(h->ds_part));                                 \
+					h->ds_part = nullptr; h->ds_part_cap = 0;                                    \
+					HIPCHK(hipMalloc((void **)&h->ds_part, need));                               \
+					h->ds_part_cap = need;                                                       \
+				}                                                                                \
+				const dim3 gt((unsigned)vb, (unsigned)ns);                                       \
+				if (INPUT == IN_U8)                                                              \
+					hipLaunchKernelGGL((score_ds_tile_kernel<PT, uint8_t>), gt, dim3(256), 0, st, \
+						(const uint8_t *)rows, (int)M, md, per, h->ds_part);                     \
+				else                                                                             \
+					hipLaunchKernelGGL((score_ds_tile_kernel<PT, double>), gt, dim3(256), 0, st, \
+						(const double *)rows, (int)M, md, per, h->ds_part);                      \
+				hipLaunchKernelGGL((score_ds_tile_epilogue<PT>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, \
+					(int)M, md, ns, h->ds_part, h->recs, h->counters, out8, valid);              \
+			} else if (INPUT == IN_U8)                                                           \
 				hipLaunchKernelGGL((score_ds_kernel<2 * KK + 2, SB, uint8_t>), grid, dim3(SB), 0, st, \
 					(const uint8_t *)rows, (int)M, md, h->recs, h->counters, out8, valid);      \
 			else                                                                                 \
