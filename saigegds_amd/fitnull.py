@@ -514,9 +514,11 @@ def seqFitNullGLMM_SPA(formula: str, data: Dict[str, Any], gdsfile, trait_type: 
     CH = 4096                                  # markers per pass: bounded host memory at any M x N
     for s0 in range(0, packed_all.shape[0], CH):
         blk = packed_all[s0:s0 + CH]
-        codes = unpack_dosage_2bit(blk, n_all)
-        if not same_samples:
-            codes = codes[:, sel_a]
+        codes = None
+        if want is None or not same_samples:       # (a given variant list on all samples needs no decode)
+            codes = unpack_dosage_2bit(blk, n_all)
+            if not same_samples:
+                codes = codes[:, sel_a]
         if want is None:
             valid = codes != 3
             nv = valid.sum(axis=1)
