@@ -147,6 +147,12 @@ int sgx_burden_2bit(sgx_handle *h, const uint8_t *packed, size_t bytes_per_varia
 	size_t n_variants, size_t n_rows, const int64_t *row_ptr, const int32_t *var_idx,
 	const double *lut, double *out8, uint8_t *valid);
 
+/* Per-variant counts of a HOST 2-bit matrix on GPU `device`: n_valid[j] = samples with a call,
+ * allele_sum[j] = their alt-allele count -- the inputs of the maf / missing-rate variant filter of
+ * seqFitNullGLMM_SPA (seqSetFilterCond, R/saige_main.r:314-321).  Needs no model handle. */
+int sgx_geno_stats_2bit(const uint8_t *packed, size_t bytes_per_variant, int32_t n_samp,
+	size_t n_variants, int device, int32_t *n_valid, int32_t *allele_sum);
+
 /* Tuning / test hooks: "spa_levels" (Newton levels run in lock step before
  * stragglers go to the per-workgroup kernel), "arena_limit" (carriers; 0 = all),
  * "score_v1" (gather kernel instead of the MFMA path), "force_dense" (exact

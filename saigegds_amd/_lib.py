@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libsaigehip.so")
 
 EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
-    "sgx_set_thresholds", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64", "sgx_burden_2bit",
+    "sgx_set_thresholds", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64", "sgx_burden_2bit", "sgx_geno_stats_2bit",
     "sgx_sync", "sgx_get_stats", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
     "sgx_grm_init", "sgx_grm_init_dev", "sgx_grm_crossprod_dev", "sgx_grm_sync", "sgx_grm_free", "sgx_grm_diag", "sgx_grm_crossprod", "sgx_grm_pcg",
 )
@@ -105,6 +105,8 @@ def load():
     L.sgx_scan_f64.argtypes = [vp, vp, sz, vp, vp]
     L.sgx_burden_2bit.restype = C.c_int
     L.sgx_burden_2bit.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp, vp, vp]
+    L.sgx_geno_stats_2bit.restype = C.c_int
+    L.sgx_geno_stats_2bit.argtypes = [vp, sz, C.c_int32, sz, C.c_int, vp, vp]
     L.sgx_set_option.restype = C.c_int
     L.sgx_set_option.argtypes = [vp, C.c_char_p, C.c_longlong]
     L.sgx_sync.restype = C.c_int
@@ -255,6 +257,17 @@ class Scanner:
 
     def set_thresholds(self, maf, mac, missing, spa_pval):
         check(self._L.sgx_set_thresholds(self._h, maf, mac, missing, spa_pval))
+
+
+def geno_stats_2bit(packed: np.ndarray, n_samp: int, device: int = 0):
+    """Per-variant (n_valid, allele_sum) of a host 2-bit matrix, counted on the GPU."""
+    L = load()
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    m = packed.shape[0]
+    nv, sm = np.empty(m, dtype=np.int32), np.empty(m, dtype=np.int32)
+    check(L.sgx_geno_stats_2bit(packed.ctypes.data, packed.shape[1], int(n_samp), m, int(device),
+                                nv.ctypes.data, sm.ctypes.data))
+    return nv, sm
 
 
 class GrmOperator:

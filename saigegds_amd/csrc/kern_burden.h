@@ -35,3 +35,32 @@ burden_collapse_kernel(const uint8_t *__restrict__ packed, size_t bpv, int N,
 	for (int s = 0; s < 16; s++)
 		if (d * 16 + s < N) o[s] = acc[s];
 }
+
+// per-variant counts of a 2-bit matrix: n_valid (codes != 3) and the allele sum (seqSetFilterCond's
+// maf / missing-rate inputs, R/saige_main.r:314-321).  One workgroup per variant.
+__global__ void __launch_bounds__(256)
+geno_stats_kernel(const uint8_t *__restrict__ packed, size_t bpv, int N, int *__restrict__ n_valid,
+	int *__restrict__ allele_sum)
+{
+	__shared__ int sh[2][4];
+	const size_t j = blockIdx.x;
+	const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + j * bpv);
+	const int ndw = (N + 15) >> 4;
+	int nv = 0, sm = 0;
+	for (int d = threadIdx.x; d < ndw; d += 256) {
+		const uint32_t km = keep_mask(N - d * 16);
+		const uint32_t w = row[d];
+		const uint32_t lo = w & LO_MASK & km, hi = (w >> 1) & LO_MASK & km;
+		const uint32_t miss = lo & hi;
+		nv += __popc(km & LO_MASK) - __popc(miss);
+		sm += __popc(lo & ~miss) + 2 * __popc(hi & ~miss);
+	}
+	nv = wave_sum_i(nv); sm = wave_sum_i(sm);
+	const int lane = threadIdx.x & (WAVE - 1), wid = threadIdx.x / WAVE;
+	if (lane == 0) { sh[0][wid] = nv; sh[1][wid] = sm; }
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		n_valid[j] = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+		allele_sum[j] = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+	}
+}

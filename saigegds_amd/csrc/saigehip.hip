@@ -841,6 +841,37 @@ extern "C" int sgx_burden_2bit(sgx_handle *h, const uint8_t *packed, size_t bpv,
 	return SGX_OK;
 }
 
+// per-variant n_valid and allele sum of a host 2-bit matrix (no model handle needed)
+extern "C" int sgx_geno_stats_2bit(const uint8_t *packed, size_t bpv, int32_t n_samp, size_t n_variants,
+	int device, int32_t *n_valid, int32_t *allele_sum)
+{
+	if (n_variants == 0) return SGX_OK;
+	if (!packed || !n_valid || !allele_sum) return fail(SGX_EINVAL, "sgx_geno_stats_2bit: NULL buffer");
+	if (n_samp <= 0 || bpv < (size_t)(n_samp + 3) / 4)
+		return fail(SGX_EINVAL, "Invalid length of dosages: bytes_per_variant=%zu < ceil(N/4)", bpv);
+	HIPCHK(hipSetDevice(device));
+	const size_t dbpv = ((size_t)(n_samp + 15) / 16) * 4;
+	const size_t chunk = std::max<size_t>(1, std::min<size_t>(n_variants, ((size_t)1 << 30) / dbpv));
+	uint8_t *dpk = nullptr; int *dn = nullptr, *ds = nullptr;
+	HIPCHK(hipMalloc((void **)&dpk, chunk * dbpv));
+	hipError_t e = hipMalloc((void **)&dn, chunk * sizeof(int));
+	if (e == hipSuccess) e = hipMalloc((void **)&ds, chunk * sizeof(int));
+	int rc = SGX_OK;
+	for (size_t off = 0; off < n_variants && e == hipSuccess; off += chunk) {
+		const size_t m = std::min(chunk, n_variants - off);
+		e = hipMemset(dpk, 0, m * dbpv);
+		if (e == hipSuccess) e = hipMemcpy2D(dpk, dbpv, packed + off * bpv, bpv, std::min(bpv, dbpv), m, hipMemcpyHostToDevice);
+		if (e != hipSuccess) break;
+		hipLaunchKernelGGL(geno_stats_kernel, dim3((unsigned)m), dim3(256), 0, 0, dpk, dbpv, (int)n_samp, dn, ds);
+		e = hipGetLastError();
+		if (e == hipSuccess) e = hipMemcpy(n_valid + off, dn, m * sizeof(int), hipMemcpyDeviceToHost);
+		if (e == hipSuccess) e = hipMemcpy(allele_sum + off, ds, m * sizeof(int), hipMemcpyDeviceToHost);
+	}
+	(void)hipFree(dpk); (void)hipFree(dn); (void)hipFree(ds);
+	if (e != hipSuccess) rc = fail(SGX_EHIP, "sgx_geno_stats_2bit: %s", hipGetErrorString(e));
+	return rc;
+}
+
 extern "C" int sgx_synth_2bit_dev(sgx_handle *h, uint8_t *packed_dev, size_t bpv, int32_t n_samp,
 	size_t M, uint64_t first_variant, uint64_t seed, const uint32_t *thr_dev)
 {

@@ -505,6 +505,11 @@ def seqFitNullGLMM_SPA(formula: str, data: Dict[str, Any], gdsfile, trait_type: 
         var_ids = np.asarray(src.read("variant.id"))
     packed_all = np.asarray(packed_all)
     want = None if variant_id is None else set(int(v) for v in variant_id)
+    gpu_counts = None
+    if want is None and n_samp == n_all and operator_factory is None:
+        # all samples selected: the per-variant counts of the filter come from the GPU
+        from ._lib import geno_stats_2bit
+        gpu_counts = geno_stats_2bit(packed_all, n_all)
     if variant_id is None and verbose:
         print("Filtering variants:")
     same_samples = (n_samp == n_all)
@@ -515,6 +520,17 @@ def seqFitNullGLMM_SPA(formula: str, data: Dict[str, Any], gdsfile, trait_type: 
     for s0 in range(0, packed_all.shape[0], CH):
         blk = packed_all[s0:s0 + CH]
         codes = None
+        if gpu_counts is not None:
+            nv = gpu_counts[0][s0:s0 + CH].astype(np.int64)
+            ac = gpu_counts[1][s0:s0 + CH].astype(np.int64)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                af = ac / (2.0 * nv)
+            mafv = np.minimum(af, 1 - af)
+            v = (mafv >= maf) & ((n_samp - nv) / n_samp <= missing_rate)
+            loc = np.flatnonzero(v)
+            keep_idx.append(loc + s0)
+            keep_packed.append(np.ascontiguousarray(blk[loc]))
+            continue
         if want is None or not same_samples:       # (a given variant list on all samples needs no decode)
             codes = unpack_dosage_2bit(blk, n_all)
             if not same_samples:

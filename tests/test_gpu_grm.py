@@ -64,3 +64,19 @@ def test_pcg_matches_oracle(grm1k):
         # iteration cap honoured
         _, itg = op.pcg(w, [1.0, 5.0], b, 3, 1e-30)
         assert itg == 3
+
+
+def test_geno_stats_match_numpy_counts():
+    """sgx_geno_stats_2bit: per-variant n_valid and allele sum (the fit's variant filter)."""
+    import os
+    from saigegds_amd._lib import geno_stats_2bit
+    from saigegds_amd.gds import unpack_dosage_2bit
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "grm1k_10k_snp.npz"))
+    packed = g["packed"][:3000].copy()
+    packed[5, :40] = 0xFF          # a stretch of missing calls
+    packed[7] = 0xFF               # an all-missing variant
+    codes = unpack_dosage_2bit(packed, 1000).astype(np.int64)
+    nv, sm = geno_stats_2bit(packed, 1000)
+    assert np.array_equal(nv, (codes != 3).sum(axis=1))
+    assert np.array_equal(sm, np.where(codes != 3, codes, 0).sum(axis=1))
+    assert nv[7] == 0 and sm[7] == 0
