@@ -40,10 +40,11 @@ __device__ __forceinline__ void cgf_pass(double t, int nnz, const double *__rest
 	double v[2] = {0, 0};
 	for (int k = threadIdx.x; k < nnz; k += BLOCK) {
 		const double g = gl[k], m = ml[k], om = 1 - m;
-		const double e = exp(-g * t);
-		const double d = om * e + m;
-		v[0] += m * g / d;                       // SPATest.cpp:64
-		const double t2 = (om * m * g * g * e) / (d * d);   // :79
+		const double mg = m * g, e = fast_exp(-g * t);
+		const double d = fma(om, e, m);
+		const double rr = isfinite(d) ? fast_rcp(d) : 0.0;
+		v[0] = fma(mg, rr, v[0]);                // SPATest.cpp:64
+		const double t2 = om * mg * g * e * rr * rr;   // :79
 		if (isfinite(t2)) v[1] += t2;            // :80
 	}
 	block_sum<2, BLOCK>(v, sh);
@@ -57,7 +58,7 @@ __device__ __forceinline__ double korg_pass(double t, int nnz, const double *__r
 	double v[1] = {0};
 	for (int k = threadIdx.x; k < nnz; k += BLOCK) {
 		const double g = gl[k], m = ml[k];
-		v[0] += log(1 - m + m * exp(g * t));     // SPATest.cpp:49
+		v[0] += fast_log(fma(m, fast_exp(g * t), 1 - m));   // SPATest.cpp:49
 	}
 	block_sum<1, BLOCK>(v, sh);
 	return v[0];

@@ -99,71 +99,6 @@ __device__ __forceinline__ void root_feed(RootState &s, double K1s, double K2s, 
 	root_step(s, NAsigma);
 }
 
-// reciprocal of d > 0 to double precision without the IEEE division sequence
-__device__ __forceinline__ double fast_rcp(double d)
-{
-	double r = __builtin_amdgcn_rcp(d);
-	r = fma(fma(-d, r, 1.0), r, r);
-	r = fma(fma(-d, r, 1.0), r, r);
-	return r;
-}
-
-// exp(x) in double precision: x = n ln2 + r, |r| <= ln2/2, degree-13 Taylor
-// polynomial (truncation 4e-18), scaled by 2^n.  Relative error ~2e-16; overflow
-// gives +inf and underflow 0 as exp() does.  About half the instructions of the
-// device-library exp.
-__device__ __forceinline__ double fast_exp(double x)
-{
-	const double n = rint(x * 1.4426950408889634074);
-	double r = fma(-n, 6.93147180369123816490e-01, x);     // ln2 hi
-	r = fma(-n, 1.90821492927058770002e-10, r);             // ln2 lo
-	double p = 1.6059043836821613e-10;                      // 1/13!
-	p = fma(p, r, 2.08767569878681e-09);
-	p = fma(p, r, 2.505210838544172e-08);
-	p = fma(p, r, 2.755731922398589e-07);
-	p = fma(p, r, 2.7557319223985893e-06);
-	p = fma(p, r, 2.48015873015873e-05);
-	p = fma(p, r, 1.984126984126984e-04);
-	p = fma(p, r, 1.388888888888889e-03);
-	p = fma(p, r, 8.333333333333333e-03);
-	p = fma(p, r, 4.1666666666666664e-02);
-	p = fma(p, r, 1.6666666666666666e-01);
-	p = fma(p, r, 0.5);
-	p = fma(p, r, 1.0);
-	p = fma(p, r, 1.0);
-	double y = ldexp(p, (int)n);
-	y = (x > 709.782712893384) ? INFINITY : y;
-	y = (x < -745.1332191019412) ? 0.0 : y;
-	return (x != x) ? x : y;
-}
-
-// log(x) for x > 0: x = 2^e m, m in [sqrt(1/2), sqrt(2)), log m = 2 atanh(s),
-// s = (m-1)/(m+1), |s| <= 0.1716, series to s^21 (truncation 2e-17 relative).
-__device__ __forceinline__ double fast_log(double x)
-{
-	if (!(x > 0) || !isfinite(x)) return log(x);             // 0, negative, inf, NaN: library semantics
-	int e = __builtin_amdgcn_frexp_exp(x);
-	double m = __builtin_amdgcn_frexp_mant(x);               // [0.5, 1)
-	const bool lo = m < 0.70710678118654752440;
-	m = lo ? m + m : m;
-	e = lo ? e - 1 : e;
-	const double s = (m - 1.0) * fast_rcp(m + 1.0);
-	const double z = s * s;
-	double p = 1.0 / 21.0;
-	p = fma(p, z, 1.0 / 19.0);
-	p = fma(p, z, 1.0 / 17.0);
-	p = fma(p, z, 1.0 / 15.0);
-	p = fma(p, z, 1.0 / 13.0);
-	p = fma(p, z, 1.0 / 11.0);
-	p = fma(p, z, 1.0 / 9.0);
-	p = fma(p, z, 1.0 / 7.0);
-	p = fma(p, z, 1.0 / 5.0);
-	p = fma(p, z, 1.0 / 3.0);
-	p = fma(p, z, 1.0);
-	const double de = (double)e;
-	return fma(de, 6.93147180369123816490e-01, fma(2.0 * s, p, de * 1.90821492927058770002e-10));
-}
-
 __global__ void fastmath_selftest_kernel(const double *x, double *y, int nt)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
