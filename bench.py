@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--pool-gb", type=float, default=120.0, help="max HBM for resident genotypes")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget; 0 = skip")
     ap.add_argument("--seed", type=int, default=20260)
+    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
+                    help="library streams per GPU: with 2 the SPA stage of one step runs under the score stage of the next")
     args = ap.parse_args()
 
     import torch
@@ -105,10 +107,14 @@ def main():
         sc.sync()
     t_gen = time.time() - t_gen
 
+    lanes = args.lanes if pool >= 2 else 1     # two steps in flight need two result buffers
+    sc.set_option("lanes", lanes)
+
     def run_step(i):
+        # asynchronous: the library queues the step on one of its streams (alternating with two
+        # lanes); its HIP-event stage times are collected after the timed region
         b = i % pool
         sc.scan_2bit_dev(packed[b].data_ptr(), bpv, block, out[b].data_ptr(), valid[b].data_ptr())
-        return sc.stats()       # syncs the handle's stream; HIP-event kernel times
 
     def barrier():
         torch.cuda.synchronize()
@@ -118,13 +124,14 @@ def main():
 
     for i in range(warmup):
         run_step(i)
+    sc.stats_total(reset=True)      # syncs; drops the warm-up steps from the sums
 
     # ---- timed region -------------------------------------------------------
     barrier()
     t0 = time.perf_counter()
-    st_all = []
     for i in range(steps):
-        st_all.append(run_step(warmup + i))
+        run_step(warmup + i)
+    sc.sync()
     if world > 1:
         # the path's one exchange step: result table to rank 0
         used = sorted({(warmup + i) % pool for i in range(steps)})
@@ -143,15 +150,26 @@ def main():
     # ---- per-kernel figures (rank 0's launches) ----------------------------
     # HIP events recorded by the library on ITS stream around the score stage
     # (score_mfma_kernel + its 40 us epilogue) and around the SPA stage (spa3_* kernels).
-    ms_score = float(np.mean([s["ms_score"] for s in st_all]))
-    ms_spa = float(np.mean([s["ms_spa"] for s in st_all]))
-    n_spa = int(np.sum([s["n_spa"] for s in st_all]))
-    n_valid = int(np.sum([s["n_valid"] for s in st_all]))
+    tot, ncalls = sc.stats_total(reset=True)
+    assert ncalls == steps, (ncalls, steps)
+    # the same kernel with nothing running beside it (one lane, a few extra steps outside the timed region)
+    iso_ms = None
+    if lanes > 1:
+        sc.set_option("lanes", 1)
+        for i in range(min(3, pool)):
+            run_step(i)
+        ti, ni = sc.stats_total(reset=True)
+        iso_ms = ti["ms_score"] / ni
+        sc.set_option("lanes", lanes)
+    ms_score = tot["ms_score"] / steps
+    ms_spa = tot["ms_spa"] / steps
+    n_spa = int(tot["n_spa"])
+    n_valid = int(tot["n_valid"])
     nv_tot = steps * block
     alg_bytes = block * (math.ceil(n / 4) + 64)      # ceil(N/4)+64 B per variant
     # dominant kernel = the one launch that streams the packed genotypes (the SPA
     # stage is ~30 short launches, none longer than it; profiles/r01_*_kernel_stats.csv)
-    score_kernel = "score_mfma_kernel" if args.k <= 4 else "score2b_kernel"
+    score_kernel = "score_mfma_kernel"        # every K <= 16: one launch per column group (K <= 3: one)
     achieved = alg_bytes / (ms_score * 1e-3) / 1e9
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "r01_pmc_score.json")
@@ -163,12 +181,16 @@ def main():
         "bound": "hbm", "kernel": score_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms_score, 4),
+        "alone": None if iso_ms is None else {
+            "avg_launch_ms": round(iso_ms, 4), "achieved": round(alg_bytes / (iso_ms * 1e-3) / 1e9, 2),
+            "frac": round(alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+            "note": "same kernel with one lane (no SPA stage of the previous step running beside it), 3 steps outside the timed region"},
         "stages": {
-            "score": {"avg_ms": round(ms_score, 4), "launches_per_step": int(st_all[0]["score_launches"])},
-            "spa": {"avg_ms": round(ms_spa, 4), "launches_per_step": int(st_all[0]["spa_launches"]),
+            "score": {"avg_ms": round(ms_score, 4), "launches_per_step": int(tot["score_launches"] // steps)},
+            "spa": {"avg_ms": round(ms_spa, 4), "launches_per_step": int(tot["spa_launches"] // steps),
                     "variants_per_step": n_spa / max(1, steps),
-                    "dense_fallback": int(np.sum([s["n_spa_dense"] for s in st_all])),
-                    "slow_path": int(np.sum([s["n_spa_slow"] for s in st_all]))},
+                    "dense_fallback": int(tot["n_spa_dense"]),
+                    "slow_path": int(tot["n_spa_slow"])},
         },
         "whole_step_gbs": round(alg_bytes * steps / elapsed / 1e9, 2),
     }
@@ -236,7 +258,7 @@ def main():
                             f"{wl['trait']} trait" + (f" prevalence {wl['prevalence']}" if wl['trait'] == 'binary' else ""),
                 "n_samples": n, "variants_per_step_per_gpu": block, "n_covariates": args.k,
                 "maf_law": "10^U(-3.3,-0.3), 10% alt-major, missing 1e-3", "thresholds": "mac=10 missing=0.1 spa.pval=0.05",
-                "resident_blocks": pool, "sharding": f"variants x{world}",
+                "resident_blocks": pool, "sharding": f"variants x{world}", "lanes": lanes,
                 "frac_spa": round(n_spa / max(1, nv_tot), 5), "frac_valid": round(n_valid / max(1, nv_tot), 5),
                 "gen_seconds": round(t_gen, 2),
             },

@@ -156,11 +156,17 @@ int sgx_geno_stats_2bit(const uint8_t *packed, size_t bytes_per_variant, int32_t
 /* Tuning / test hooks: "spa_levels" (Newton levels run in lock step before
  * stragglers go to the per-workgroup kernel), "arena_limit" (carriers; 0 = all),
  * "score_v1" (gather kernel instead of the MFMA path), "force_dense" (exact
- * g_pos/g_neg pass for every SPA variant).  Results never depend on them. */
+ * g_pos/g_neg pass for every SPA variant), "lanes" (1 or 2: with 2, successive sgx_scan_2bit_dev
+ * calls alternate between two streams with their own workspace, so the SPA stage of one block runs
+ * under the score stage of the next; call sgx_sync() before reading any output).  Results never
+ * depend on them. */
 int sgx_set_option(sgx_handle *h, const char *name, long long value);
 
 int sgx_sync(sgx_handle *h);
-int sgx_get_stats(sgx_handle *h, sgx_stats *st);
+int sgx_get_stats(sgx_handle *h, sgx_stats *st);          /* the most recent call */
+/* sums over all calls completed since the last reset (ms_* are per-stage event times: with two
+ * lanes they overlap in wall time) */
+int sgx_get_stats_total(sgx_handle *h, sgx_stats *st, uint64_t *n_calls, int reset);
 
 /* Device-side helpers for the benchmark / synthetic GDS generator ---------- */
 

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libsaigehip.so")
 EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
     "sgx_set_thresholds", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64", "sgx_burden_2bit", "sgx_geno_stats_2bit",
-    "sgx_sync", "sgx_get_stats", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
+    "sgx_sync", "sgx_get_stats", "sgx_get_stats_total", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
     "sgx_grm_init", "sgx_grm_init_dev", "sgx_grm_crossprod_dev", "sgx_grm_sync", "sgx_grm_free", "sgx_grm_diag", "sgx_grm_crossprod", "sgx_grm_pcg",
 )
 
@@ -113,6 +113,8 @@ def load():
     L.sgx_sync.argtypes = [vp]
     L.sgx_get_stats.restype = C.c_int
     L.sgx_get_stats.argtypes = [vp, C.POINTER(SgxStats)]
+    L.sgx_get_stats_total.restype = C.c_int
+    L.sgx_get_stats_total.argtypes = [vp, C.POINTER(SgxStats), C.POINTER(C.c_uint64), C.c_int]
     L.sgx_row_stride.restype = sz
     L.sgx_row_stride.argtypes = [C.c_int32]
     L.sgx_synth_2bit_dev.restype = C.c_int
@@ -251,6 +253,12 @@ class Scanner:
         st = SgxStats()
         check(self._L.sgx_get_stats(self._h, C.byref(st)))
         return st.as_dict()
+
+    def stats_total(self, reset: bool = True):
+        """Sums over the calls completed since the last reset -> (dict, n_calls); syncs."""
+        st, n = SgxStats(), C.c_uint64(0)
+        check(self._L.sgx_get_stats_total(self._h, C.byref(st), C.byref(n), 1 if reset else 0))
+        return st.as_dict(), int(n.value)
 
     def set_option(self, name: str, value: int):
         check(self._L.sgx_set_option(self._h, name.encode(), int(value)))

@@ -109,6 +109,17 @@ struct sgx_handle {
 	sgx_stats stats{};
 	bool force_v1 = false;            // SAIGEHIP_SCORE_V1=1: gather kernel instead of the MFMA path
 	bool stats_pending = false;
+	// Two lanes ("lanes" option): device-resident scans alternate between this handle and a twin
+	// with its own stream and workspace (the model arrays are shared), so that the SPA stage of
+	// one block of variants runs while the score stage of the next one streams the genotypes.
+	// Score stages never overlap each other (the later one waits for the earlier one's event).
+	sgx_handle *twin = nullptr;       // owned by the primary handle
+	sgx_handle *owner = nullptr;      // set in the twin
+	bool shares_model = false;        // twin: dF .. dFl belong to the owner
+	int next_lane = 0;                // primary: which lane takes the next _dev call
+	sgx_handle *last_issued = nullptr;// primary: lane of the most recent call
+	sgx_stats total{};                // primary: sums over harvested calls (sgx_get_stats_total)
+	uint64_t total_calls = 0;
 };
 
 static int set_dev(sgx_handle *h)
@@ -143,6 +154,7 @@ extern "C" int sgx_set_thresholds(sgx_handle *h, double maf, double mac, double 
 	h->md.thr_mac = thr_or(mac, -1);
 	h->md.thr_missing = thr_or(missing, 1);
 	h->md.thr_spa = thr_or(spa_pval, 0.05);
+	if (h->twin) return sgx_set_thresholds(h->twin, maf, mac, missing, spa_pval);
 	return SGX_OK;
 }
 
@@ -220,6 +232,30 @@ static bool fit_xvx_inverse(const sgx_model *m, double *out)
 		for (int b = 0; b < K; b++) out[(size_t)b * K + a] = (double)M[(size_t)a * K + b];
 	for (int a = 0; a < K * K; a++) if (!std::isfinite(out[a])) return false;
 	return true;
+}
+
+// stream, events, counters and the SPA buffers whose size does not depend on the call
+static int alloc_workspace(sgx_handle *h)
+{
+	const int N = h->md.N;
+	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	HIPCHK(hipMalloc((void **)&h->counters, 8 * sizeof(int)));
+	HIPCHK(hipHostMalloc((void **)&h->h_counters, 8 * sizeof(int), hipHostMallocDefault));
+	HIPCHK(hipMalloc((void **)&h->cursor, sizeof(unsigned long long)));
+	for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&h->ev[i]));
+	// SPA scratch: one (adj, mu) list of N entries per resident workgroup
+	hipDeviceProp_t prop;
+	HIPCHK(hipGetDeviceProperties(&prop, h->device));
+	h->spa_grid = prop.multiProcessorCount * 2;
+	h->n_cu = prop.multiProcessorCount;
+	h->scratch_stride = 2 * (((size_t)N + 63) & ~(size_t)63);
+	HIPCHK(hipMalloc((void **)&h->scratch, h->scratch_stride * sizeof(double) * h->spa_grid));
+	if (!h->md.quant) {
+		// arena of (adj, mu) carrier lists shared by all flagged variants of a call
+		h->arena_cap = std::min<unsigned long long>(400000000ull, std::max<unsigned long long>(4000000ull, (unsigned long long)N * 1024ull));
+		HIPCHK(hipMalloc((void **)&h->arena, h->arena_cap * sizeof(double2)));
+	}
+	return SGX_OK;
 }
 
 extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
@@ -364,27 +400,9 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		for (int g = 0; g < h->mfe.ngroups; g++) h->mf[g].Fl = h->dFl + fl_off[g];
 	}
 	md.F = h->dF; md.X = h->dX; md.y = h->dy; md.mu = h->dmu; md.mu2 = h->dmu2; md.XM = h->dXM;
-	hipError_t e;
-#define TRYH(x) do { e = (x); if (e != hipSuccess) { sgx_free(h); return fail(SGX_EHIP, "%s: %s", #x, hipGetErrorString(e)); } } while (0)
-	TRYH(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-	TRYH(hipMalloc((void **)&h->counters, 8 * sizeof(int)));
-	TRYH(hipHostMalloc((void **)&h->h_counters, 8 * sizeof(int), hipHostMallocDefault));
-	TRYH(hipMalloc((void **)&h->cursor, sizeof(unsigned long long)));
-	for (int i = 0; i < 3; i++) TRYH(hipEventCreate(&h->ev[i]));
-	// SPA scratch: one (adj, mu) list of N entries per resident workgroup
-	hipDeviceProp_t prop;
-	TRYH(hipGetDeviceProperties(&prop, device));
-	h->spa_grid = prop.multiProcessorCount * 2;
-	h->n_cu = prop.multiProcessorCount;
-	h->scratch_stride = 2 * (((size_t)N + 63) & ~(size_t)63);
-	TRYH(hipMalloc((void **)&h->scratch, h->scratch_stride * sizeof(double) * h->spa_grid));
-	if (!quant) {
-		// arena of (adj, mu) carrier lists shared by all flagged variants of a call
-		h->arena_cap = std::min<unsigned long long>(400000000ull, std::max<unsigned long long>(4000000ull, (unsigned long long)N * 1024ull));
-		TRYH(hipMalloc((void **)&h->arena, h->arena_cap * sizeof(double2)));
-	}
+	rc = alloc_workspace(h);
+	if (rc) { sgx_free(h); return rc; }
 #undef TRY
-#undef TRYH
 	{ const char *e = getenv("SAIGEHIP_SCORE_V1"); h->force_v1 = e && e[0] == '1'; }
 	*out = h;
 	return SGX_OK;
@@ -395,10 +413,14 @@ extern "C" void sgx_free(sgx_handle *h)
 	if (!h) return;
 	(void)hipSetDevice(h->device);
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
-	(void)hipFree(h->dF); (void)hipFree(h->dX); (void)hipFree(h->dy);
-	(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->fallback); (void)hipFree(h->fb_spa2); (void)hipFree(h->heads);
+	if (h->twin) { sgx_free(h->twin); h->twin = nullptr; }
+	if (!h->shares_model) {
+		(void)hipFree(h->dF); (void)hipFree(h->dX); (void)hipFree(h->dy);
+		(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->dFl);
+	}
+	(void)hipFree(h->fallback); (void)hipFree(h->fb_spa2); (void)hipFree(h->heads);
 	(void)hipFree(h->arena); (void)hipFree(h->cursor); (void)hipFree(h->segcnt); (void)hipFree(h->segpart); (void)hipFree(h->chunks); (void)hipFree(h->partial);
-	(void)hipFree(h->dFl); (void)hipFree(h->mf_acc);
+	(void)hipFree(h->mf_acc);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
 	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid); (void)hipFree(h->stage_pk); (void)hipFree(h->ds_part);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
@@ -627,13 +649,34 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 	else if (n == "arena_limit") { if (value < 0) return fail(SGX_EINVAL, "arena_limit < 0"); h->arena_limit = (unsigned long long)value; }
 	else if (n == "score_v1") h->force_v1 = value != 0;
 	else if (n == "force_dense") h->force_dense = value != 0;
+	else if (n == "lanes") {
+		if (value != 1 && value != 2) return fail(SGX_EINVAL, "lanes must be 1 or 2");
+		if (h->owner) return fail(SGX_EINVAL, "lanes: not on a twin");
+		int rc = sgx_sync(h);
+		if (rc) return rc;
+		if (value == 1 && h->twin) { sgx_free(h->twin); h->twin = nullptr; h->next_lane = 0; }
+		if (value == 2 && !h->twin) {
+			sgx_handle *t = new sgx_handle();
+			t->device = h->device; t->md = h->md; t->mf_ok = h->mf_ok; t->mfe = h->mfe;
+			for (int g = 0; g < MF_MAXG; g++) { t->mf[g] = h->mf[g]; t->mf_nbfv[g] = h->mf_nbfv[g]; }
+			t->dF = h->dF; t->dX = h->dX; t->dy = h->dy; t->dmu = h->dmu; t->dmu2 = h->dmu2; t->dXM = h->dXM; t->dFl = h->dFl;
+			t->shares_model = true; t->owner = h;
+			t->spa_levels = h->spa_levels; t->arena_limit = h->arena_limit; t->force_dense = h->force_dense; t->force_v1 = h->force_v1;
+			rc = set_dev(t);
+			if (!rc) rc = alloc_workspace(t);
+			if (rc) { sgx_free(t); return rc; }
+			h->twin = t;
+		}
+		return SGX_OK;
+	}
 	else return fail(SGX_EINVAL, "sgx_set_option: unknown option '%s'", name);
+	if (h->twin) return sgx_set_option(h->twin, name, value);
 	return SGX_OK;
 }
 
-extern "C" int sgx_sync(sgx_handle *h)
+// wait for this lane's work and turn its events / counters into stats
+static int sync_lane(sgx_handle *h)
 {
-	if (!h) return fail(SGX_EINVAL, "sgx_sync: NULL handle");
 	int rc = set_dev(h);
 	if (rc) return rc;
 	HIPCHK(hipStreamSynchronize(h->stream));
@@ -648,8 +691,23 @@ extern "C" int sgx_sync(sgx_handle *h)
 		(void)hipEventElapsedTime(&c, h->ev[0], h->ev[2]);
 		h->stats.ms_score = a; h->stats.ms_spa = b; h->stats.ms_total = c;
 		h->stats_pending = false;
+		sgx_handle *p = h->owner ? h->owner : h;
+		const sgx_stats &x = h->stats;
+		p->total.n_variants += x.n_variants; p->total.n_valid += x.n_valid; p->total.n_spa += x.n_spa;
+		p->total.n_spa_dense += x.n_spa_dense; p->total.n_spa_slow += x.n_spa_slow;
+		p->total.ms_score += x.ms_score; p->total.ms_spa += x.ms_spa; p->total.ms_total += x.ms_total;
+		p->total.score_launches += x.score_launches; p->total.spa_launches += x.spa_launches;
+		p->total_calls++;
 	}
 	return SGX_OK;
+}
+
+extern "C" int sgx_sync(sgx_handle *h)
+{
+	if (!h) return fail(SGX_EINVAL, "sgx_sync: NULL handle");
+	int rc = sync_lane(h);
+	if (!rc && h->twin) rc = sync_lane(h->twin);
+	return rc;
 }
 
 extern "C" int sgx_get_stats(sgx_handle *h, sgx_stats *st)
@@ -657,7 +715,18 @@ extern "C" int sgx_get_stats(sgx_handle *h, sgx_stats *st)
 	if (!h || !st) return fail(SGX_EINVAL, "sgx_get_stats: NULL argument");
 	int rc = sgx_sync(h);
 	if (rc) return rc;
-	*st = h->stats;
+	*st = (h->last_issued && h->last_issued != h) ? h->last_issued->stats : h->stats;   // the most recent call
+	return SGX_OK;
+}
+
+extern "C" int sgx_get_stats_total(sgx_handle *h, sgx_stats *st, uint64_t *n_calls, int reset)
+{
+	if (!h || !st) return fail(SGX_EINVAL, "sgx_get_stats_total: NULL argument");
+	int rc = sgx_sync(h);
+	if (rc) return rc;
+	*st = h->total;
+	if (n_calls) *n_calls = h->total_calls;
+	if (reset) { h->total = sgx_stats{}; h->total_calls = 0; }
 	return SGX_OK;
 }
 
@@ -676,9 +745,20 @@ extern "C" int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev, size_
 		return fail(SGX_EINVAL, "sgx_scan_2bit_dev: packed_dev must be 16-byte aligned");
 	int rc = set_dev(h);
 	if (rc) return rc;
-	rc = ensure_recs(h, M);
+	sgx_handle *lane = h, *other = nullptr;
+	if (h->twin) {
+		lane = h->next_lane ? h->twin : h;
+		other = h->next_lane ? h : h->twin;
+		h->next_lane ^= 1;
+	}
+	rc = sync_lane(lane);                // the lane's previous call is done: keep its stats (events are reused)
 	if (rc) return rc;
-	return launch_scan<IN_2BIT>(h, packed_dev, bpv, M, out8_dev, valid_dev);
+	h->last_issued = lane;
+	rc = ensure_recs(lane, M);
+	if (rc) return rc;
+	// score stages do not overlap: this one starts after the other lane's has ended
+	if (other && other->stats_pending) HIPCHK(hipStreamWaitEvent(lane->stream, other->ev[1], 0));
+	return launch_scan<IN_2BIT>(lane, packed_dev, bpv, M, out8_dev, valid_dev);
 }
 
 static int ensure_stage(sgx_handle *h, size_t in_bytes, size_t M)

@@ -49,14 +49,21 @@ def gather_table(out_local, valid_local, n_variants: int, group=None, dst: int =
     return out, valid
 
 
-def scan_sharded(scanner, packed_local_dev, bpv: int, group=None, n_variants: Optional[int] = None):
+def scan_sharded(scanner, packed_local_dev, bpv: int, group=None, n_variants: Optional[int] = None,
+                 block: int = 50_000):
     """Scan this rank's HBM-resident shard and gather the table on rank 0.
     ``packed_local_dev``: torch uint8 tensor [m_r, bpv] on this rank's GPU."""
     import torch
     m = packed_local_dev.shape[0]
     out = torch.empty((m, 8), dtype=torch.float64, device=packed_local_dev.device)
     valid = torch.empty((m,), dtype=torch.uint8, device=packed_local_dev.device)
-    scanner.scan_2bit_dev(packed_local_dev.data_ptr(), bpv, m, out.data_ptr(), valid.data_ptr())
+    # blocks of 50 000 variants (.bl_size, R/assoc_single.r:204) on the library's two lanes: the SPA
+    # stage of one block runs under the score stage of the next
+    scanner.set_option("lanes", 2)
+    for lo in range(0, m, block):
+        hi = min(m, lo + block)
+        scanner.scan_2bit_dev(packed_local_dev[lo:hi].data_ptr(), bpv, hi - lo, out[lo:hi].data_ptr(),
+                              valid[lo:hi].data_ptr())
     scanner.sync()
     if n_variants is None:
         import torch.distributed as dist

@@ -211,7 +211,61 @@ def test_fallback_paths_give_identical_rows(option, value, counter):
     np.testing.assert_allclose(out[v][:, 3:7], base[v][:, 3:7], rtol=1e-11)
 
 
+def test_two_lanes_give_identical_tables():
+    """"lanes" = 2: successive device-resident scans alternate between two streams with their own
+    workspace; every block's table must equal the single-lane one, and the totals must add up."""
+    import torch
+    sm, packed = _synthetic_case(3001, 2400, "binary", 0.05, seed=31)
+    dev = torch.device("cuda", 0)
+    with _scanner(sm) as sc:
+        bpv = sc.row_stride()
+        pk = torch.zeros((4, 600, bpv), dtype=torch.uint8, device=dev)
+        pk[:, :, :packed.shape[1]] = torch.from_numpy(packed.reshape(4, 600, -1)).to(dev)
+        res = {}
+        for lanes in (1, 2):
+            sc.set_option("lanes", lanes)
+            out = torch.full((4, 600, 8), -1.0, dtype=torch.float64, device=dev)
+            valid = torch.zeros((4, 600), dtype=torch.uint8, device=dev)
+            sc.stats_total(reset=True)
+            for rep in range(3):              # lanes are reused: 12 calls
+                for b in range(4):
+                    sc.scan_2bit_dev(pk[b].data_ptr(), bpv, 600, out[b].data_ptr(), valid[b].data_ptr())
+            tot, ncalls = sc.stats_total(reset=True)
+            assert ncalls == 12 and tot["n_variants"] == 12 * 600
+            res[lanes] = (out.cpu().numpy(), valid.cpu().numpy(), tot)
+        sc.set_option("lanes", 1)
+    assert np.array_equal(res[1][1], res[2][1])
+    assert np.array_equal(np.nan_to_num(res[1][0], nan=-7.0), np.nan_to_num(res[2][0], nan=-7.0))
+    assert res[1][2]["n_spa"] == res[2][2]["n_spa"] and res[1][2]["n_valid"] == res[2][2]["n_valid"]
+    ref, ref_valid = _oracle(sm).scan_2bit(packed)
+    assert_table_close(res[2][0].reshape(-1, 8), res[2][1].reshape(-1), ref, ref_valid, what="lanes=2")
+
+
 def test_mfma_lane_map_selftest():
     """v_mfma_i32_16x16x64_i8 operand/result lane maps assumed by the score kernel."""
     from saigegds_amd import _lib
     _lib.check(_lib.load().sgx_selftest(0))
+
+
+def test_scan_sharded_single_rank_rccl():
+    """dist.scan_sharded on a one-rank RCCL group: blocks on two lanes, then the gather."""
+    import torch
+    import torch.distributed as dist
+    from saigegds_amd.dist import scan_sharded
+    sm, packed = _synthetic_case(2000, 1300, "binary", 0.1, seed=41)
+    ref, ref_valid = _oracle(sm).scan_2bit(packed)
+    dev = torch.device("cuda", 0)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=dev)
+        created = True
+    try:
+        with _scanner(sm) as sc:
+            bpv = sc.row_stride()
+            pk = torch.zeros((1300, bpv), dtype=torch.uint8, device=dev)
+            pk[:, :packed.shape[1]] = torch.from_numpy(packed).to(dev)
+            out, valid = scan_sharded(sc, pk, bpv, block=500)      # 3 blocks, ragged tail
+        assert_table_close(out.cpu().numpy(), valid.cpu().numpy(), ref, ref_valid, what="scan_sharded")
+    finally:
+        if created:
+            dist.destroy_process_group()
