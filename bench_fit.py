@@ -6,7 +6,7 @@
 
 Prints one JSON line.  Not the headline metric (that is bench.py).  The CPU figure beside it is
 the oracle's time per implicit-GRM product (one core, scaled from a marker sample) times the
-number of products the fit made; the reference's own fit is not runnable here."""
+number of products the fit made; the reference's own fit is not runnable here.  The oracle is touched only in that cpu_baseline leg."""
 import argparse
 import json
 import os

@@ -4,7 +4,8 @@ implicit-GRM mat-vec out = G'(G b)/M on 2-bit genotypes and one PCG solve.
 
     python bench_grm.py [--n-samp 430000] [--markers 100000] [--reps 5]
 
-Prints one JSON line.  Not the headline metric (that is bench.py)."""
+Prints one JSON line.  Not the headline metric (that is bench.py).  The oracle is touched only in the
+cpu_baseline leg (timing + parity check), as in bench.py."""
 import argparse
 import json
 import os

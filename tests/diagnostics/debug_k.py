@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""GPU vs oracle for one covariate count: python tools/debug_k.py K [N M]  (rows that differ)."""
+"""GPU vs oracle for one covariate count: python tests/diagnostics/debug_k.py K [N M]  (rows that differ)."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import torch  # noqa
 from saigegds_amd import synth
 from saigegds_amd._lib import Scanner

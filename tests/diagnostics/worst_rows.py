@@ -1,6 +1,6 @@
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from saigegds_amd import synth
 from saigegds_amd._lib import Scanner
 from saigegds_amd.nullmod import init_nullmod
