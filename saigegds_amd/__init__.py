@@ -8,8 +8,8 @@ The compute lives in libsaigehip.so (include/saigehip.h); there is no CPU path.
 """
 from .nullmod import NullModel, ScanModel, init_nullmod, load_modobj  # noqa: F401
 from .assoc import GenotypeSource, seqAssocGLMM_SPA  # noqa: F401
-from .fitnull import FittedNullModel, seqFitNullGLMM_SPA  # noqa: F401
-from .aggregate import (AggrParamBeta, pACAT, seqAssocGLMM_spaACAT_O, seqAssocGLMM_spaACAT_V,  # noqa: F401
+from .fitnull import FittedNullModel, glmmHeritability, seqFitNullGLMM_SPA  # noqa: F401
+from .aggregate import (AggrParamBeta, pACAT, pACAT2, seqAssocGLMM_spaACAT_O, seqAssocGLMM_spaACAT_V,  # noqa: F401
                         seqAssocGLMM_spaBurden)
 
 __version__ = "0.1.0"

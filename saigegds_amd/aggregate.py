@@ -80,6 +80,17 @@ def pACAT(p: Sequence[float], w: Optional[Sequence[float]] = None) -> float:
     return acat_pval(p, w, throw_error=True)
 
 
+def pACAT2(p: Sequence[float], maf: Sequence[float], wbeta=(1, 25)) -> float:
+    """``pACAT2(p, maf, wbeta)`` (R/saige_main.r:150-156): ACAT with weights dbeta(maf)^2 maf (1 - maf)."""
+    p, maf = np.asarray(p, dtype=np.float64), np.asarray(maf, dtype=np.float64)
+    if len(wbeta) != 2:
+        raise ValueError("length(wbeta) == 2L is not TRUE")
+    if p.size != maf.size:
+        raise ValueError("length(p) == length(maf) is not TRUE")
+    w = _dbeta(maf, float(wbeta[0]), float(wbeta[1]))
+    return pACAT(p, w * w * maf * (1 - maf))
+
+
 def _mean_sd(x: np.ndarray):
     """``f64_mean_sd``: mean and sample sd over finite values."""
     x = x[np.isfinite(x)]

@@ -667,3 +667,19 @@ def seqFitNullGLMM_SPA(formula: str, data: Dict[str, Any], gdsfile, trait_type: 
     if verbose:
         print("Done.")
     return model
+
+
+def glmmHeritability(modobj, adjust: bool = True) -> float:
+    """``glmmHeritability(modobj, adjust)`` (R/saige_main.r:666-691): liability-scale estimate from
+    tau; for binary outcomes optionally adjusted by the prevalence (Zhou et al. 2018, Suppl. Table 7)."""
+    from .nullmod import load_modobj
+    m = load_modobj(modobj)
+    if m.trait_type == "binary":
+        tau, r = float(m.tau[1]), 1.0
+        if adjust:
+            y = np.asarray(m.y)
+            r = 2.970 + 0.372 * math.log10(float(np.sum(y == 1)) / y.size)
+        return tau / (math.pi * math.pi / 3 + tau) * r
+    if m.trait_type == "quantitative":
+        return float(m.tau[1]) / float(np.sum(m.tau))
+    raise ValueError("Invalid 'modobj$trait.type'.")

@@ -36,6 +36,10 @@ def test_pacat_matches_r_formula():
     with pytest.raises(ValueError):
         pACAT([0.1, 2.0])
     assert pACAT([1e-20, 0.5], [1.0, 1.0]) == pytest.approx(2e-20, rel=1e-6)
+    from saigegds_amd.aggregate import pACAT2, _dbeta
+    pp, mf = np.array([0.01, 0.2, 0.5]), np.array([0.001, 0.01, 0.2])
+    w = _dbeta(mf, 1, 25)
+    assert pACAT2(pp, mf) == pytest.approx(pACAT(pp, w * w * mf * (1 - mf)))
 
 
 def test_acat_oracle_agrees_with_driver_combination():

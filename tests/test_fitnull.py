@@ -138,3 +138,20 @@ def test_fit_then_scan_end_to_end_on_gpu():
     assert np.array_equal(np.asarray(res["id"]), gold["id"])
     for k, gk in [("AF.alt", "AF_alt"), ("beta", "beta"), ("SE", "SE"), ("pval", "pval")]:
         assert _mean_rel(res[k], gold[gk]) < 1e-7, k       # test_SAIGE.R:97-98
+
+
+def test_heritability_from_golden_models():
+    from saigegds_amd import glmmHeritability
+    from saigegds_amd.nullmod import NullModel
+    import math
+    for name, trait in (("saige_model.npz", "binary"), ("saige_model_quant.npz", "quantitative")):
+        m = np.load(os.path.join(GOLD, name))
+        mod = NullModel(trait_type=trait, tau=m["tau"], fitted_values=m["fitted_values"], sample_id=list(m["sample_id"]),
+                        var_ratio=m["var_ratio"], y=m["y"], V=m["V"], X1=m["X1"], XV=m["XV"], XXVX_inv=m["XXVX_inv"])
+        h = glmmHeritability(mod)
+        if trait == "binary":
+            p = float(np.mean(m["y"] == 1))
+            assert h == pytest.approx(m["tau"][1] / (math.pi ** 2 / 3 + m["tau"][1]) * (2.970 + 0.372 * math.log10(p)))
+            assert glmmHeritability(mod, adjust=False) == pytest.approx(m["tau"][1] / (math.pi ** 2 / 3 + m["tau"][1]))
+        else:
+            assert h == pytest.approx(m["tau"][1] / m["tau"].sum())
