@@ -485,3 +485,110 @@ spa3_finish(int *__restrict__ counters, SpaHead *__restrict__ heads, const doubl
 	spa_write_row(r, h->Tstat, h->var1, pval, converged, out8);
 	h->state = 0;
 }
+
+
+// ---------------------------------------------------------------------------
+// Dosage rows (RAW bytes / doubles) through the same level-synchronous stage: the list of a row
+// holds its non-zero (imputed, flipped) dosages -- for imputed data nearly every sample.
+// spa3_count_ds / spa3_fill_ds stand in for spa3_count / spa3_fill; plan, head, the Newton levels
+// and finish are shared.  INPUT is IN_U8 or IN_F64 (kern_spa.h).
+
+template <int INPUT>
+__global__ void __launch_bounds__(256)
+spa3_count_ds(const void *__restrict__ rows, size_t row_bytes, int N, int nseg, int seg_samples,
+	const SpaRec *__restrict__ recs, const int *__restrict__ counters, int *__restrict__ segcnt)
+{
+	const int lane = threadIdx.x & (WAVE - 1);
+	const int gw = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE, nw = gridDim.x * blockDim.x / WAVE;
+	const int nflag = counters[0];
+	const int nitem = nflag * nseg;
+	for (int wi = gw; wi < nitem; wi += nw) {
+		const int seg = wi / nflag, v = wi - seg * nflag;   // segment-major order
+		const SpaRec &r = recs[v];
+		const void *row = reinterpret_cast<const uint8_t *>(rows) + (size_t)r.j * row_bytes;
+		const int s0 = seg * seg_samples, s1 = min(N, s0 + seg_samples);
+		int cnt = 0;
+		for (int i = s0 + lane; i < s1; i += WAVE) cnt += (load_dosage<INPUT>(row, i, r) != 0);
+		cnt = wave_sum_i(cnt);
+		if (lane == 0) segcnt[v * nseg + seg] = cnt;
+	}
+}
+
+template <int K, int INPUT>
+__global__ void __launch_bounds__(WAVE * SPA3_FILL_WAVES)
+spa3_fill_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, int nseg, int nslice,
+	const SpaRec *__restrict__ recs, const int *__restrict__ counters, const int *__restrict__ segoff,
+	const SpaHead *__restrict__ heads, double2 *__restrict__ arena, double *__restrict__ segpart)
+{
+	constexpr int SEG = spa3_seg(K), KP = (K + 2) & ~1, PF = 8;   // PF dosages per lane in flight
+	extern __shared__ __attribute__((aligned(16))) uint8_t fill_smem[];
+	double *tab = reinterpret_cast<double *>(fill_smem);                               // [SEG][KP]
+	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	const int nflag = counters[0];
+	const int vper = (nflag + nslice - 1) / nslice;
+	for (int item = blockIdx.x; item < nseg * nslice; item += gridDim.x) {
+		const int seg = item / nslice, sl = item - seg * nslice;
+		const int vbeg = sl * vper, vend = min(nflag, vbeg + vper);
+		if (vbeg >= vend) continue;
+		__syncthreads();                     // the previous item's readers of the table are done
+		const int rows_here = min(SEG, N - seg * SEG);
+		{
+			const double2 *src = reinterpret_cast<const double2 *>(md.XM + (size_t)seg * SEG * KP);
+			double2 *dst = reinterpret_cast<double2 *>(tab);
+			for (int i = tid; i < rows_here * (KP / 2); i += WAVE * SPA3_FILL_WAVES) dst[i] = src[i];
+		}
+		__syncthreads();
+		for (int v = vbeg + wid; v < vend; v += SPA3_FILL_WAVES) {
+			const SpaHead *hd = heads + v;
+			if (hd->nnz < 0) continue;
+			const SpaRec r = recs[v];
+			const int it = v * nseg + seg;
+			const void *row = reinterpret_cast<const uint8_t *>(rows) + (size_t)r.j * row_bytes;
+			const double inv = 1 / sqrt(r.AC2);
+			double c[K];
+#pragma unroll
+			for (int a = 0; a < K; a++) c[a] = r.c[a];
+			double2 *lst = arena + hd->off + (unsigned long long)segoff[it];
+			double a12[SPA3_NSEGP];
+#pragma unroll
+			for (int a = 0; a < SPA3_NSEGP; a++) a12[a] = 0;
+			int run = 0;
+			for (int b0 = 0; b0 < rows_here; b0 += PF * WAVE) {
+				double g[PF];
+#pragma unroll
+				for (int j = 0; j < PF; j++) {
+					const int ii = b0 + j * WAVE + lane;
+					g[j] = (ii < rows_here) ? load_dosage<INPUT>(row, seg * SEG + ii, r) : 0.0;
+				}
+#pragma unroll
+				for (int j = 0; j < PF; j++) {
+					const int ii = b0 + j * WAVE + lane;
+					const bool carrier = g[j] != 0;
+					const unsigned long long mask = __ballot(carrier);
+					if (carrier) {
+						const int pos = run + __popcll(mask & ((1ull << lane) - 1ull));
+						const double *x = tab + (size_t)ii * KP;
+						double b = 0;
+#pragma unroll
+						for (int a = 0; a < K; a++) b = fma(x[a], c[a], b);
+						const double mui = x[K];
+						const double adj = (g[j] - b) * inv;
+						lst[pos] = make_double2(adj, mui);
+						a12[0] = fma(mui, g[j], a12[0]);
+						a12[1] += b;
+						if (adj > 0) a12[2] += adj; else a12[3] += adj;
+						a12[4] = fma(adj, mui, a12[4]);
+						a12[5] = fma(adj * adj, mui * (1 - mui), a12[5]);
+					}
+					run += __popcll(mask);
+				}
+			}
+#pragma unroll
+			for (int a = 0; a < SPA3_NSEGP; a++) a12[a] = wave_sum(a12[a]);
+			if (lane == 0) {
+#pragma unroll
+				for (int a = 0; a < SPA3_NSEGP; a++) segpart[(size_t)it * SPA3_NSEGP + a] = a12[a];
+			}
+		}
+	}
+}

@@ -89,6 +89,7 @@ struct sgx_handle {
 	unsigned long long arena_limit = 0;   // test hook: pretend the arena is this small (0 = real size)
 	bool force_dense = false;         // test hook: every SPA variant takes the exact dense pass
 	bool fill_attr_set = false;       // spa3_fill's dynamic LDS size has been raised above 64 KiB
+	bool fill_ds_attr_set = false;    // same for spa3_fill_ds
 	// exact-integer MFMA score path (kern_score_mfma.h)
 	bool mf_ok = false;
 	MfTab mf[MF_MAXG]{};              // one limb table per column group
@@ -621,9 +622,52 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
 				row_bytes, md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
 				h->scratch_stride, out8);                                                    \
-		} else {                                                                             \
+		} else if (h->force_v1) {                                                            \
 			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
 				row_bytes, md, h->recs, h->counters, 0, (const int *)nullptr, h->scratch,    \
+				h->scratch_stride, out8);                                                    \
+		} else {                                                                             \
+			/* dosage rows: the same level-synchronous stage over (mostly dense) lists */    \
+			const dim3 g256((unsigned)((M + 255) / 256));                                    \
+			const dim3 gchunk((unsigned)(h->n_cu * 8));                                      \
+			const dim3 gitem((unsigned)(h->n_cu * 16));                                      \
+			hipLaunchKernelGGL((spa3_count_ds<INPUT>), gitem, dim3(256), 0, st, rows,        \
+				row_bytes, md.N, h->nseg, spa3_seg(KK), h->recs, h->counters, h->segcnt);    \
+			hipLaunchKernelGGL((spa3_plan<KK>), g256, dim3(256), 0, st, md, h->nseg, h->recs,\
+				h->counters, h->cursor,                                                      \
+				(h->arena_limit ? std::min(h->arena_limit, h->arena_cap) : h->arena_cap),    \
+				h->segcnt, h->heads, h->fb_spa2, out8);                                      \
+			{                                                                                \
+				const size_t fl = (size_t)spa3_seg(KK) * (((KK) + 2) & ~1) * 8;              \
+				const int nslice = std::max(1, (2 * h->n_cu + h->nseg - 1) / h->nseg);       \
+				if (!h->fill_ds_attr_set) {                                                  \
+					HIPCHK(hipFuncSetAttribute((const void *)spa3_fill_ds<KK, INPUT>,        \
+						hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));               \
+					h->fill_ds_attr_set = true;                                              \
+				}                                                                            \
+				hipLaunchKernelGGL((spa3_fill_ds<KK, INPUT>), dim3((unsigned)std::min(h->nseg * nslice, 4 * h->n_cu)), \
+					dim3(WAVE * SPA3_FILL_WAVES), fl, st, rows, row_bytes, md, h->nseg,      \
+					nslice, h->recs, h->counters, h->segcnt, h->heads, h->arena, h->segpart);\
+			}                                                                                \
+			hipLaunchKernelGGL((spa3_head<KK>), g256, dim3(256), 0, st, md, h->nseg,         \
+				h->recs, h->counters, h->segpart, h->heads, h->chunks, h->chunk_cap,         \
+				h->fallback, h->fb_spa2, out8, h->force_dense ? 1 : 0);                      \
+			for (int lv = 0; lv < h->spa_levels; lv++) {                                     \
+				hipLaunchKernelGGL(spa3_pass, gchunk, dim3(SPA3_BLOCK), 0, st, h->counters,  \
+					h->chunks, h->heads, h->arena, h->partial);                              \
+				hipLaunchKernelGGL(spa3_advance, g256, dim3(256), 0, st, h->counters,        \
+					h->heads, h->partial);                                                   \
+			}                                                                                \
+			hipLaunchKernelGGL(spa3_korg, gchunk, dim3(SPA3_BLOCK), 0, st, h->counters,      \
+				h->chunks, h->heads, h->arena, h->partial);                                  \
+			hipLaunchKernelGGL(spa3_finish, g256, dim3(256), 0, st, h->counters, h->heads,   \
+				h->partial, h->recs, h->fb_spa2, out8);                                      \
+			/* stragglers / arena overflow, then the exact dense g_pos, g_neg pass */        \
+			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
+				row_bytes, md, h->recs, h->counters, 3, h->fb_spa2, h->scratch,              \
+				h->scratch_stride, out8);                                                    \
+			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
+				row_bytes, md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
 				h->scratch_stride, out8);                                                    \
 		}                                                                                    \
 		break;
@@ -631,7 +675,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 #undef CASE
 		}
 		HIPCHK(hipGetLastError());
-		h->stats.spa_launches = (INPUT == IN_2BIT) ? (uint32_t)(8 + 2 * h->spa_levels) : 1u;
+		h->stats.spa_launches = (INPUT == IN_2BIT || !h->force_v1) ? (uint32_t)(8 + 2 * h->spa_levels) : 1u;
 	}
 	HIPCHK(hipEventRecord(h->ev[2], st));
 	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
