@@ -476,6 +476,7 @@ static dim3 mf_grid(int n_cu, size_t rows, int ntile, int *tps)
 {
 	const int vt = (int)((rows + MF_VPB - 1) / MF_VPB);
 	int sk = std::max(1, (n_cu * 2 * 4 + vt / 2) / vt);
+	sk = std::min(sk, std::max(1, ntile / 24));   // a split shorter than ~24 tiles is mostly prologue and atomics
 	if (sk >= 6) sk = (sk + 7) & ~7;
 	sk = std::min(sk, std::max(1, ntile / 2));
 	*tps = (ntile + sk - 1) / sk;
