@@ -19,6 +19,7 @@ struct DevModel {
 	double S_a[KMAX];
 	double Xmu[KMAX];   // X' mu
 	double Xsum[KMAX];  // X' 1
+	double spa_xmax;    // series SPA stage (kern_spa4.h): largest max_i |g_i t| it accepts
 };
 
 // a variant handed from the score stage to the SPA stage
@@ -33,8 +34,19 @@ struct SpaRec {
 	double S;         // score sum (y-mu).adj, unscaled
 	double var2;      // sum mu2 adj^2, unscaled (no variance ratio)
 	double sum_gmu;   // sum_i G_i mu_i over the (imputed, flipped) dosages
+	double tscale;    // power of two near the first Newton point of the root search (kern_spa4.h)
 	double c[KMAX];   // c' = XVX_inv_XV * G
 };
+
+// 2^floor(log2 |t|) of the first Newton point t = (q~ - m1)/var2 of getroot_K1_fast, from the score
+// stage's sums: q~ - m1 = Tstat/sqrt(r), Tstat = S/sqrt(AC2), var2 = var2_score/AC2
+__device__ __forceinline__ double spa_tscale(double S, double var2, double AC2, double r)
+{
+	const double t = fabs(S) * sqrt(AC2) / (sqrt(r) * var2);
+	int e = (t > 0 && isfinite(t)) ? ilogb(t) : 0;
+	e = max(-400, min(400, e));
+	return ldexp(1.0, e);
+}
 
 // ---------------------------------------------------------------------------
 // device math: Rmath stand-ins (see oracle/saige_oracle.c for the CPU twins)

@@ -94,7 +94,7 @@ score2b_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, DevModel m
 			SpaRec r;
 			r.j = j; r.minus = h.minus; r.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
 			r.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); r.has_gmu = 0; r.sum_gmu = 0;
-			r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc;
+			r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc; r.tscale = spa_tscale(Ssc, v2sc, r.AC2, md.r);
 			for (int a = 0; a < 4; a++) r.lut[a] = h.lut[a];
 			for (int a = 0; a < KMAX; a++) r.c[a] = (a < md.K) ? cbuf[a] : 0.0;
 			recs[slot] = r;
@@ -167,7 +167,7 @@ score_ds_kernel(const T *__restrict__ ds, int M, DevModel md, SpaRec *__restrict
 			SpaRec r;
 			r.j = j; r.minus = h.minus; r.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
 			r.nnz = 0; r.has_gmu = 0; r.sum_gmu = 0;
-			r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc;
+			r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc; r.tscale = spa_tscale(Ssc, v2sc, r.AC2, md.r);
 			// dosage rows carry real values: lut[3] holds the imputed value, the
 			// SPA kernel re-reads the row itself
 			for (int a = 0; a < 4; a++) r.lut[a] = h.lut[a];
@@ -290,7 +290,7 @@ score_ds_tile_epilogue(int M, DevModel md, int nsplit, const double *__restrict_
 		SpaRec r;
 		r.j = j; r.minus = h.minus; r.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
 		r.nnz = 0; r.has_gmu = 0; r.sum_gmu = 0;
-		r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc;
+		r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc; r.tscale = spa_tscale(Ssc, v2sc, r.AC2, md.r);
 		// dosage rows carry real values: lut[3] holds the imputed value, the SPA kernel re-reads the row
 		for (int a = 0; a < 4; a++) r.lut[a] = h.lut[a];
 		for (int a = 0; a < KMAX; a++) r.c[a] = (a < md.K) ? cbuf[a] : 0.0;

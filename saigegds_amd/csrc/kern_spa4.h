@@ -1,0 +1,585 @@
+// kern_spa4.h -- SPA stage v4: the saddlepoint sums of a flagged variant as a power series in t.
+// Part of libsaigehip.so (single translation unit: saigehip.hip).
+#pragma once
+#include "kern_spa4_tab.h"
+
+// What the reference evaluates per Newton step and root (SPATest.cpp:42-83) are sums over the
+// carriers I of the variant,
+//     Korg(t) = sum_I log(1 - mu_i + mu_i e^{g_i t}),   K1 = Korg',   K2 = Korg'',
+// i.e. the cumulant generating function of sum_I g_i Bernoulli(mu_i) and its derivatives.  Its
+// Taylor coefficients are the cumulants
+//     kappa_n = sum_I g_i^n c_n(mu_i),      c_2 = mu (1 - mu),  c_{n+1} = mu (1 - mu) dc_n/dmu,
+// and the series converges for |g_i t| < sqrt(logit(mu_i)^2 + pi^2) (the nearest zero of
+// 1 - mu + mu e^x), i.e. with ratio <= |g t| / pi per term.  At biobank sizes g_i ~ 1/sqrt(2 N maf)
+// is small: for every variant with maf above ~1 % (98 % of all carriers of a scan at N = 430 000)
+// max |g_i t| stays under ~0.7 and sixteen cumulants give Korg, K1 and K2 to better than 1e-13 --
+// under the rounding noise of the reference's own double sums (tests/diagnostics/cumulant_proto.py).
+//
+// So the stage is ONE pass over the carriers of the flagged variants (spa4_moments: the cumulant
+// sums beside the sums the scalars need anyway), after which every Newton evaluation of
+// getroot_K1_fast, both roots, and the Lugannani-Rice tail are polynomial evaluations by one thread
+// per variant (spa4_solve).  No carrier list is stored and none is re-read.
+//
+// A variant leaves this path for the exact exp/log kernels (spa2_kernel, then spa_kernel) when
+//   * any point the root search evaluates has gmax |t| > spa_xmax (= a quarter of the smallest
+//     convergence radius over the model's mu_i), or
+//   * there the last two terms of the K2 series (the slowest of the three) exceed 1e-13 of its sum, or
+//   * the g_pos / g_neg bound test of kern_spa2.h is not decisive.
+// Those are the rare variants (few carriers, large g): their lists are short and the exact kernels
+// cheap.  Results do not depend on which path a variant takes beyond ~1e-13.
+//
+//   spa4_moments  workgroups pull (sample segment, slice of the flagged variants) items from a queue;
+//                 the segment's X rows and mu are staged in LDS, then one wave per variant compacts
+//                 its carriers through an LDS queue and accumulates, 64 carriers at a time,
+//                 sum mu G, sum b, sum max/min(adj, 0), kappa_1, kappa_2, max |adj| and
+//                 kappa'_n = sum (adj ts)^n c_n(mu)/n!  (n = 3..NC; ts = a power of two near the
+//                 expected root, so the scaled sums decay like the series itself)
+//   spa4_solve    per variant: ordered sums over the segments, the scalars of saige_main.cpp:369-381,
+//                 the cutoff exit (SPATest.cpp:319-321), both root searches (root_feed / root_step of
+//                 kern_spa2.h, fed from the series), tail probabilities, SE, the output row
+
+#define SPA4_WAVES 8
+#define SPA4_NS (SPA4_NC + 5)    /* partial sums per (variant, segment) */
+#define SPA4_TAIL_TOL 1e-13
+
+// T_n = y^n c_n(mu)/n! for n = 3..NC added to acc[n - 3];  y = adj * ts.
+// The polynomials in u are summed over explicit powers of u (one multiply-add per coefficient with
+// the coefficient as the constant operand), not by Horner's rule, whose running value would need a
+// register copy of every coefficient first.
+__device__ __forceinline__ void spa4_cum_terms(double y, double u, double d, double *acc)
+{
+	double up[SPA4_CDEG];          // u^k
+	up[0] = 1.0; up[1] = u;
+#pragma unroll
+	for (int k = 2; k < SPA4_CDEG; k++) up[k] = up[k - 1] * u;
+	const double y2 = y * y;
+	double pe = y2 * u;            // y^n u      (even n, starting at n = 2)
+	double po = pe * y * d;        // y^n u d    (odd n, starting at n = 3)
+#pragma unroll
+	for (int n = 3; n <= SPA4_NC; n++) {
+		const int deg = (n - 2) / 2;      // degree of the polynomial in u
+		double b = SPA4_CUM[n][0];
+#pragma unroll
+		for (int k = 1; k <= deg; k++) b = fma(SPA4_CUM[n][k], up[k], b);
+		if (n & 1) {
+			acc[n - 3] = fma(po, b, acc[n - 3]);
+			po *= y2;
+		} else {
+			pe *= y2;
+			acc[n - 3] = fma(pe, b, acc[n - 3]);
+		}
+	}
+}
+
+// Sum V doubles per lane over the wave with ~V shuffles instead of 6 V: at every step a lane keeps
+// half of its values and hands the other half to its partner (xor 32, 16, .. 2), the last step adds
+// the two lanes that hold the same value.  Afterwards v[0] of lane l is the total of value
+//   idx = 12 b5 + 6 b4 + 3 b3 + 2 b2 + b1   (b_k = bit k of l; idx with b2 = b1 = 1 is padding)
+// for V <= 24.  The tree is fixed, so the result does not depend on scheduling.
+template <int V>
+__device__ __forceinline__ int wave_reduce_scatter24(double (&x)[V], int lane)
+{
+	static_assert(V <= 24 && V > 18, "written for 19..24 values");
+	int idx = 0;
+#pragma unroll
+	for (int st = 0; st < 5; st++) {
+		const int o = 32 >> st;                                  // 32 16 8 4 2
+		const int n = st == 0 ? 24 : st == 1 ? 12 : st == 2 ? 6 : st == 3 ? 4 : 2;   // values held (3 padded to 4)
+		const int half = n / 2;
+		const bool up = (lane & o) != 0;
+#pragma unroll
+		for (int i = 0; i < half; i++) {
+			// slots past the V values of the first step, and the pad slot of the fourth, hold zero
+			const bool hi_real = st == 0 ? (i + half < V) : !(st == 3 && i + half == 3);
+			const double xh = hi_real ? x[i + half] : 0.0;
+			const double send = up ? x[i] : xh;
+			const double keep = up ? xh : x[i];
+			x[i] = keep + __shfl_xor(send, o, WAVE);
+		}
+		idx += up ? (st == 0 ? 12 : st == 1 ? 6 : st == 2 ? 3 : st == 3 ? 2 : 1) : 0;
+	}
+	x[0] += __shfl_xor(x[0], 1, WAVE);
+	return idx;
+}
+
+#define SPA4_VPER 128            /* flagged variants whose parameters a workgroup holds in LDS at a time */
+
+// dynamic LDS of spa4_moments<K>: the segment's table + the parameter slice
+__host__ __device__ constexpr size_t spa4_lds_bytes(int K)
+{
+	return (size_t)spa3_seg(K) * ((K + 2) & ~1) * 8 + (size_t)SPA4_VPER * (8 + 8 * (K + 6));
+}
+
+// One workgroup per CU.  Item = (sample segment, slice of SPA4_VPER flagged variants): the segment's X
+// rows and mu and the slice's parameters are staged in LDS; one wave per variant, a lane owns SEG/64
+// consecutive samples of the segment and walks its carriers in lock step with the other lanes.
+template <int K>
+__global__ void __launch_bounds__(WAVE * SPA4_WAVES)
+spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg, int v0, int vcap,
+	const SpaRec *__restrict__ recs, const int *__restrict__ counters, double *__restrict__ segpart, int abl)
+{
+	constexpr int SEG = spa3_seg(K), KP = (K + 2) & ~1;
+	constexpr int LDW = SEG / 16 / WAVE > 0 ? SEG / 16 / WAVE : 1;     // dwords (of 16 samples) per lane
+	constexpr int NLANE = SEG / 16 / LDW;                              // lanes that own samples
+	static_assert(LDW == 1 || LDW == 2 || LDW == 4, "segment sizes 512..4096");
+	extern __shared__ __attribute__((aligned(16))) uint8_t fill_smem[];
+	double *tab = reinterpret_cast<double *>(fill_smem);                                  // [SEG][KP]
+	double *pd = tab + (size_t)SEG * KP;                                                  // [K + 6][VPER]: inv, ts, c[K], lut[4]
+	int *pj = reinterpret_cast<int *>(pd + (size_t)(K + 6) * SPA4_VPER);                 // [VPER] row, [VPER] flip mask
+	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	const int nflag = min(counters[0] - v0, vcap);
+	if (nflag <= 0) return;
+	// the (segment, slice) items in segment-major order, an equal contiguous share per workgroup:
+	// a workgroup restages the table only when its range crosses into the next segment
+	const int nslice = (nflag + SPA4_VPER - 1) / SPA4_VPER;
+	const long long nitem = (long long)nseg * nslice;
+	const int it0 = (int)(nitem * blockIdx.x / gridDim.x), it1 = (int)(nitem * (blockIdx.x + 1) / gridDim.x);
+	int seg = -1;
+	size_t row_off = 0;                                                           // this lane's bytes of a row
+	bool mine = false;
+	int samp0 = 0;                                                                // first sample of the lane
+	auto load_row = [&](int vl) -> uint4 {                                      // .x .. of the first LDW are used
+		uint4 w = make_uint4(0u, 0u, 0u, 0u);
+		if (mine && !(abl & 16)) {
+			const uint8_t *p = packed + (size_t)pj[vl] * bpv + row_off;
+			if (LDW == 4) w = *reinterpret_cast<const uint4 *>(p);
+			else if (LDW == 2) { const uint2 t = *reinterpret_cast<const uint2 *>(p); w.x = t.x; w.y = t.y; }
+			else w.x = *reinterpret_cast<const uint32_t *>(p);
+		}
+		return w;
+	};
+	for (int it = it0; it < it1; it++) {
+		const int sg = it / nslice, vb = (it - sg * nslice) * SPA4_VPER;
+		const int nv = min(SPA4_VPER, nflag - vb);
+		__syncthreads();                     // the previous item's readers are done
+		if (sg != seg) {
+			seg = sg;
+			const int rows = min(SEG, N - seg * SEG);
+			const double2 *src = reinterpret_cast<const double2 *>(md.XM + (size_t)seg * SEG * KP);
+			double2 *dst = reinterpret_cast<double2 *>(tab);
+			for (int i = tid; i < rows * (KP / 2); i += WAVE * SPA4_WAVES) dst[i] = src[i];
+			row_off = ((size_t)seg * (SEG / 16) + (size_t)lane * LDW) * 4;
+			mine = lane < NLANE && row_off + 4 * LDW <= bpv;
+			samp0 = seg * SEG + lane * LDW * 16;
+		}
+		for (int i = tid; i < nv; i += WAVE * SPA4_WAVES) {
+			const SpaRec &r = recs[v0 + vb + i];
+			pj[i] = r.j;
+			pj[SPA4_VPER + i] = r.minus ? (int)0xAAAAAAAAu : 0;
+			pd[i] = 1 / sqrt(r.AC2);
+			pd[SPA4_VPER + i] = r.tscale;
+#pragma unroll
+			for (int a = 0; a < K; a++) pd[(2 + a) * SPA4_VPER + i] = r.c[a];
+#pragma unroll
+			for (int a = 0; a < 4; a++) pd[(2 + K + a) * SPA4_VPER + i] = r.lut[a];
+		}
+		__syncthreads();
+		// rows two variants ahead of the one being worked on
+		uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0;
+		if (wid < nv) w0 = load_row(wid);
+		if (wid + SPA4_WAVES < nv) w1 = load_row(wid + SPA4_WAVES);
+		for (int vl = wid; vl < nv; vl += SPA4_WAVES) {
+			const uint4 wv = w0;
+			w0 = w1;
+			if (vl + 2 * SPA4_WAVES < nv) w1 = load_row(vl + 2 * SPA4_WAVES);
+			const double inv = pd[vl], ts = pd[SPA4_VPER + vl];
+			const uint32_t zx = (uint32_t)pj[SPA4_VPER + vl];
+			double c[K];
+#pragma unroll
+			for (int a = 0; a < K; a++) c[a] = pd[(2 + a) * SPA4_VPER + vl];
+			const double *lut = pd + (2 + K) * SPA4_VPER + vl;       // dosage of code k at lut[k * VPER]
+			// 0 sum mu*G, 1 sum b, 2 sum max(adj,0), 3 sum min(adj,0), 4 sum adj*mu, 5 sum adj^2 mu(1-mu),
+			// 6.. kappa'_3..NC; max |adj| apart
+			double acc[SPA4_NS - 1], gmax = 0;
+#pragma unroll
+			for (int a = 0; a < SPA4_NS - 1; a++) acc[a] = 0;
+			// carrier masks: bit b of lo -> dword (b & 1), sample b >> 1 of it; hi the same for dwords 2, 3
+			const uint32_t wd0 = wv.x, wd1 = wv.y, wd2 = wv.z, wd3 = wv.w;
+			auto nzm = [&](uint32_t w, int k) -> uint32_t {
+				return (mine && k < LDW) ? nz_fields((w ^ zx) & keep_mask(N - samp0 - 16 * k)) : 0u;
+			};
+			uint32_t lo = nzm(wd0, 0) | (nzm(wd1, 1) << 1), hi = nzm(wd2, 2) | (nzm(wd3, 3) << 1);
+			if (abl & 4) lo = hi = 0;
+			// Software pipeline: the table row and the dosage of a lane's next carrier are read from
+			// LDS before the arithmetic of the current one, into the other of two register sets.
+			struct Car { double x[K + 1], G; bool ok; };
+			auto fetch = [&](Car &cr) {
+				cr.ok = (lo | hi) != 0;
+				if (cr.ok) {
+					const bool inlo = lo != 0;
+					const int b = __ffs(inlo ? lo : hi) - 1;
+					if (inlo) lo &= lo - 1; else hi &= hi - 1;
+					const int dwi = (inlo ? 0 : 2) + (b & 1), sid = b >> 1;
+					const uint32_t wsel = dwi == 0 ? wd0 : dwi == 1 ? wd1 : dwi == 2 ? wd2 : wd3;
+					const uint32_t code = (wsel >> (2 * sid)) & 3u;
+					const double *x = tab + (size_t)((lane * LDW + dwi) * 16 + sid) * KP;
+#pragma unroll
+					for (int a = 0; a <= K; a++) cr.x[a] = x[a];
+					cr.G = lut[code * SPA4_VPER];
+				}
+			};
+			auto work = [&](const Car &cr) {
+				double bb = 0;
+#pragma unroll
+				for (int a = 0; a < K; a++) bb = fma(cr.x[a], c[a], bb);
+				const double mui = cr.x[K], G = cr.G;
+				const double adj = (G - bb) * inv;
+				const double u = mui * (1 - mui);
+				acc[0] = fma(mui, G, acc[0]);
+				acc[1] += bb;
+				if (adj > 0) acc[2] += adj; else acc[3] += adj;
+				acc[4] = fma(adj, mui, acc[4]);
+				acc[5] = fma(adj * adj, u, acc[5]);
+				gmax = fmax(gmax, fabs(adj));
+				if (!(abl & 1)) spa4_cum_terms(adj * ts, u, 1 - 2 * mui, &acc[6]);
+			};
+			Car ca, cb;
+			fetch(ca);
+			for (;;) {
+				if (!__ballot(ca.ok)) break;
+				fetch(cb);
+				if (ca.ok) work(ca);
+				if (!__ballot(cb.ok)) break;
+				fetch(ca);
+				if (cb.ok) work(cb);
+			}
+			if (abl & 32) { if (lane == 0) segpart[(size_t)seg * SPA4_NS * vcap + (vb + vl)] = acc[0] + gmax; continue; }
+			const int idx = wave_reduce_scatter24(acc, lane);
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o, WAVE));
+			const size_t base = (size_t)seg * SPA4_NS * vcap + (vb + vl);
+			if (!(lane & 1) && (lane & 6) != 6 && idx < SPA4_NS - 1) segpart[base + (size_t)idx * vcap] = acc[0];
+			if (lane == 1) segpart[base + (size_t)(SPA4_NS - 1) * vcap] = gmax;
+		}
+	}
+}
+
+// the carrier series of one variant
+struct Spa4Series {
+	double k1, k2;               // kappa_1 = sum g mu, kappa_2 = sum g^2 mu (1 - mu)
+	double kp[SPA4_NC - 2];      // kappa'_n = kappa_n ts^n / n!, n = 3..NC
+	double ts, gmax;
+};
+
+// K1 (without "- q"), K2 and Korg sums at t (SPATest.cpp:49,64,79); false when the series cannot
+// be trusted there
+__device__ __forceinline__ bool spa4_eval(const Spa4Series &S, double xmax, double t, double &K1s, double &K2s, double &K0s)
+{
+	const double its = 1 / S.ts, tau = t * its;       // ts is a power of two
+	double p0 = 0, p1 = 0, p2 = 0;
+#pragma unroll
+	for (int n = SPA4_NC; n >= 3; n--) {
+		const double kn = S.kp[n - 3];
+		p0 = fma(p0, tau, kn);
+		p1 = fma(p1, tau, (double)n * kn);
+		p2 = fma(p2, tau, (double)(n * (n - 1)) * kn);
+	}
+	const double tau2 = tau * tau;
+	K0s = fma(t, S.k1, fma(0.5 * t * t, S.k2, p0 * tau2 * tau));
+	K1s = S.k1 + fma(t, S.k2, p1 * tau2 * its);
+	K2s = fma(p2 * tau, its * its, S.k2);
+	// the last two terms of the K2 series, tau^(NC-2) and tau^(NC-3)
+	double tp = tau2;                   // tau^2
+	tp *= tp;                           // tau^4
+	double t13 = tp * tp * tp * tau;    // tau^13
+	static_assert(SPA4_NC == 16, "tail powers are written for NC = 16");
+	const double tail = (fabs((double)(SPA4_NC * (SPA4_NC - 1)) * S.kp[SPA4_NC - 3] * t13 * tau) +
+		fabs((double)((SPA4_NC - 1) * (SPA4_NC - 2)) * S.kp[SPA4_NC - 4] * t13)) * its * its;
+	return S.gmax * fabs(t) <= xmax && tail <= SPA4_TAIL_TOL * fabs(K2s) && isfinite(K2s);
+}
+
+// getroot_K1_fast (SPATest.cpp:139-184) on the series; false = leave to the exact kernels
+__device__ __forceinline__ bool spa4_root(const Spa4Series &S, double xmax, double q, double NAmu, double NAsigma, RootState &s)
+{
+	root_begin(s, q, 0, 0);
+	root_feed(s, S.k1, S.k2, NAmu, NAsigma, 0.0, true);      // t = 0: K1 = kappa_1, K2 = kappa_2, Korg = 0
+	while (s.active) {
+		double K1s, K2s, K0s;
+		if (!spa4_eval(S, xmax, s.tnew, K1s, K2s, K0s)) return false;
+		root_feed(s, K1s, K2s, NAmu, NAsigma, K0s, true);
+	}
+	return true;
+}
+
+// one thread per flagged variant of the round [v0, v0 + vcap)
+template <int K>
+__global__ void __launch_bounds__(256)
+spa4_solve(DevModel md, int nseg, int v0, int vcap, const SpaRec *__restrict__ recs, int *__restrict__ counters,
+	const double *__restrict__ segpart, int *__restrict__ fb_dense, int *__restrict__ fb_spa2,
+	double *__restrict__ out8, int force_dense, int force_exact)
+{
+	const int v = blockIdx.x * blockDim.x + threadIdx.x;
+	if (v >= min(counters[0] - v0, vcap)) return;
+	const SpaRec r = recs[v0 + v];
+	double a[SPA4_NS];
+#pragma unroll
+	for (int x = 0; x < SPA4_NS; x++) a[x] = 0;
+	for (int s = 0; s < nseg; s++) {
+		const double *p = segpart + (size_t)s * SPA4_NS * vcap + v;
+#pragma unroll
+		for (int x = 0; x < SPA4_NS - 1; x++) a[x] += p[(size_t)x * vcap];
+		a[SPA4_NS - 1] = fmax(a[SPA4_NS - 1], p[(size_t)(SPA4_NS - 1) * vcap]);
+	}
+	// scalars of saige_main.cpp:369-381
+	const double inv = 1 / sqrt(r.AC2);
+	double xmu_c = 0, xsum_c = 0;
+#pragma unroll
+	for (int x = 0; x < K; x++) { xmu_c = fma(md.Xmu[x], r.c[x], xmu_c); xsum_c = fma(md.Xsum[x], r.c[x], xsum_c); }
+	const double Tstat = r.S * inv;                       // q - m1, :380
+	const double var2 = r.var2 / r.AC2, var1 = var2 * md.r;
+	const double m1 = (a[0] - xmu_c) * inv;
+	const double qtilde = Tstat / sqrt(var1) * sqrt(var2) + m1;   // :381
+	const double sdev = qtilde - m1, qinv = -sdev + m1;
+	const double pn_in = d_pchisq1_upper(sdev * sdev / var2);
+	if (fabs(qtilde - m1) / sqrt(var2) < 2.0) {           // SPATest.cpp:319-321
+		spa_write_row(r, Tstat, var1, pn_in, true, out8);
+		return;
+	}
+	// g_pos / g_neg bound test (kern_spa2.h)
+	const double nb = (xsum_c - a[1]) * inv;
+	const double L = a[2] + fmax(-nb, 0.0), U = a[3] + fmin(-nb, 0.0);
+	const double mar = 1e-9 * (fabs(L) + fabs(U) + fabs(qtilde) + fabs(qinv));
+	if (force_dense || !(qtilde < L - mar && qtilde > U + mar && qinv < L - mar && qinv > U + mar)) {
+		fb_dense[atomicAdd(&counters[2], 1)] = v0 + v;
+		return;
+	}
+	Spa4Series S;
+	S.k1 = a[4]; S.k2 = a[5]; S.ts = r.tscale; S.gmax = a[SPA4_NS - 1];
+#pragma unroll
+	for (int x = 0; x < SPA4_NC - 2; x++) S.kp[x] = a[6 + x];
+	const double NAmu = m1 - a[4], NAsigma = var2 - a[5];
+	RootState s1, s2;
+	if (force_exact || !spa4_root(S, md.spa_xmax, qtilde, NAmu, NAsigma, s1) ||
+		!spa4_root(S, md.spa_xmax, qinv, NAmu, NAsigma, s2)) {
+		fb_spa2[atomicAdd(&counters[3], 1)] = v0 + v;
+		return;
+	}
+	double pval;
+	bool converged = true;
+	if (s1.converged && s2.converged) {
+		const double p1 = lugannani_rice(s1.root, s1.Kcur, s1.K2cur, qtilde, NAmu, NAsigma);
+		const double p2 = lugannani_rice(s2.root, s2.Kcur, s2.K2cur, qinv, NAmu, NAsigma);
+		pval = fabs(p1) + fabs(p2);
+		if (pval != 0 && pn_in / pval > 1000) pval = pn_in;   // SPATest.cpp:368-371
+	} else {
+		pval = pn_in;
+		converged = false;
+	}
+	spa_write_row(r, Tstat, var1, pval, converged, out8);
+}
+
+// ---------------------------------------------------------------------------
+// Exact path for the variants the series does not cover (rare variants: few carriers, large g t; or
+// a strong signal): one workgroup of 16 waves per variant, workgroups pull variants from a queue,
+// the longer lists first.  The workgroup scans the packed row into an index list (ascending sample
+// order), turns it into the (adj, mu) list (gathers of the X rows) with the carrier sums, and then
+// runs Saddle_Prob_Fast exactly as the reference does -- every K1/K2 evaluation one sweep of the
+// workgroup over its list, both roots in the same sweep, Korg with the sweep that is predicted to be
+// the last (kern_spa2.h).  The lists live in the workgroup's slice of global scratch (N entries: any
+// variant fits).
+
+#define SPA5_BLOCK 512
+#define SPA5_BIG 2048            /* lists longer than this are started first (they set the kernel's tail) */
+
+// cgf_terms (kern_spa3.h) with the Korg term switched at run time (workgroup-uniform)
+__device__ __noinline__ void cgf_terms_rt(double g, double m, double t, bool with_k, double &k1, double &k2, double &k0)
+{
+	const double om = 1 - m, mg = m * g, c2 = om * mg * g;
+	const double e = fast_exp(-g * t);
+	const double d = fma(om, e, m);
+	const double rr = isfinite(d) ? fast_rcp(d) : 0.0;
+	k1 = fma(mg, rr, k1);
+	const double tt = c2 * e * rr * rr;
+	if (isfinite(tt)) k2 += tt;
+	if (with_k) k0 += isfinite(d) ? fma(g, t, fast_log(d)) : fast_log(fma(m, fast_exp(g * t), om));
+}
+
+// bytes of scratch per workgroup: (adj, mu) list + index list, N entries each
+__host__ __device__ inline size_t spa5_wg_bytes(int N) { return (((size_t)N + 63) & ~(size_t)63) * (16 + 4); }
+
+template <int K>
+__global__ void __launch_bounds__(SPA5_BLOCK)
+spa5_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, const SpaRec *__restrict__ recs,
+	int *__restrict__ counters, const int *__restrict__ todo, int *__restrict__ cursor,
+	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8)
+{
+	constexpr int KP = (K + 2) & ~1, NW = SPA5_BLOCK / WAVE;
+	__shared__ double sh[6 * NW];
+	__shared__ int shi[NW];
+	__shared__ int sh_vi;
+	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	double2 *glist = reinterpret_cast<double2 *>(scratch + (size_t)blockIdx.x * spa5_wg_bytes(N));
+	uint32_t *ilist = reinterpret_cast<uint32_t *>(glist + (((size_t)N + 63) & ~(size_t)63));
+	const int ntodo = counters[3];
+	const int nvec = (int)(min((size_t)((N + 63) >> 6) * 16, bpv) / 16);      // uint4 pieces (64 samples) of a row
+	const int per = ((nvec + NW - 1) / NW + WAVE - 1) & ~(WAVE - 1);          // pieces per wave, whole wave steps
+	for (;;) {
+		__syncthreads();                         // sh_vi, shi and the lists of the previous variant are free
+		if (tid == 0) sh_vi = atomicAdd(cursor, 1);
+		__syncthreads();
+		const int vi = sh_vi;
+		if (vi >= 2 * ntodo) break;
+		// two rounds over the list: the long lists first, then the short ones
+		const bool big_round = vi < ntodo;
+		const int v = todo[big_round ? vi : vi - ntodo];
+		if ((recs[v].nnz > SPA5_BIG) != big_round) continue;
+		const SpaRec &r = recs[v];               // fields are read where they are used
+		const uint4 *row = reinterpret_cast<const uint4 *>(packed + (size_t)r.j * bpv);
+		const uint32_t zx = r.minus ? 0xAAAAAAAAu : 0u;
+		const double lut0 = r.lut[0], lut1 = r.lut[1], lut2 = r.lut[2], lut3 = r.lut[3];
+		// ---- index list: sample | code << 30, ascending.  Wave w owns pieces [w per, (w+1) per).
+		auto masks = [&](int p, uint32_t (&ww)[4], uint32_t (&z)[4]) -> int {
+			uint4 w = make_uint4(0u, 0u, 0u, 0u);
+			if (p < nvec) w = row[p];
+			ww[0] = w.x; ww[1] = w.y; ww[2] = w.z; ww[3] = w.w;
+			int cnt = 0;
+#pragma unroll
+			for (int k = 0; k < 4; k++) { z[k] = nz_fields((ww[k] ^ zx) & keep_mask(N - p * 64 - 16 * k)); cnt += __popc(z[k]); }
+			return cnt;
+		};
+		int cnt_w = 0;
+		for (int it = 0; it < per; it += WAVE) {
+			uint32_t ww[4], z[4];
+			cnt_w += masks(wid * per + it + lane, ww, z);
+		}
+		cnt_w = wave_sum_i(cnt_w);
+		if (lane == 0) shi[wid] = cnt_w;
+		__syncthreads();
+		int o_w = 0, nnz = 0;
+#pragma unroll
+		for (int w = 0; w < NW; w++) { if (w < wid) o_w += shi[w]; nnz += shi[w]; }
+		for (int it = 0; it < per; it += WAVE) {
+			uint32_t ww[4], z[4];
+			const int p = wid * per + it + lane;
+			const int cnt = masks(p, ww, z);
+			if (!__ballot(cnt != 0)) continue;
+			int incl = cnt;
+#pragma unroll
+			for (int o = 1; o < WAVE; o <<= 1) {
+				const int up = __shfl_up(incl, o, WAVE);
+				if (lane >= o) incl += up;
+			}
+			int o2 = o_w + incl - cnt;
+			o_w += __shfl(incl, WAVE - 1, WAVE);
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				uint32_t zz = z[k];
+				while (zz) {
+					const int b = __ffs(zz) - 1;
+					zz &= zz - 1;
+					ilist[o2++] = (uint32_t)(p * 64 + 16 * k + (b >> 1)) | (((ww[k] >> b) & 3u) << 30);
+				}
+			}
+		}
+		__syncthreads();                         // publishes the index list to the workgroup
+		// ---- (adj, mu) list + carrier sums (kern_spa2.h)
+		const double inv = 1 / sqrt(r.AC2);
+		double c[K];
+#pragma unroll
+		for (int a = 0; a < K; a++) c[a] = r.c[a];
+		double a6[6] = {0, 0, 0, 0, 0, 0};
+		for (int k0 = tid; k0 < nnz; k0 += 2 * SPA5_BLOCK) {
+			uint32_t e[2];
+			double xv[2][KP];
+#pragma unroll
+			for (int j = 0; j < 2; j++) e[j] = (k0 + j * SPA5_BLOCK < nnz) ? ilist[k0 + j * SPA5_BLOCK] : 0u;
+#pragma unroll
+			for (int j = 0; j < 2; j++) {
+				const double *x = md.XM + (size_t)(e[j] & 0x3FFFFFFFu) * KP;
+#pragma unroll
+				for (int a = 0; a < KP; a += 2) {
+					const double2 t2 = *reinterpret_cast<const double2 *>(x + a);
+					xv[j][a] = t2.x; xv[j][a + 1] = t2.y;
+				}
+			}
+#pragma unroll
+			for (int j = 0; j < 2; j++) {
+				const int k = k0 + j * SPA5_BLOCK;
+				if (k >= nnz) continue;
+				const uint32_t code = e[j] >> 30;
+				const double G = (code & 2u) ? ((code & 1u) ? lut3 : lut2) : ((code & 1u) ? lut1 : lut0);
+				double b = 0;
+#pragma unroll
+				for (int a = 0; a < K; a++) b = fma(xv[j][a], c[a], b);
+				const double mui = xv[j][K];
+				const double adj = (G - b) * inv;
+				glist[k] = make_double2(adj, mui);
+				a6[0] = fma(mui, G, a6[0]);
+				a6[1] += b;
+				if (adj > 0) a6[2] += adj; else a6[3] += adj;
+				a6[4] = fma(adj, mui, a6[4]);
+				a6[5] = fma(adj * adj, mui * (1 - mui), a6[5]);
+			}
+		}
+		block_sum<6, SPA5_BLOCK>(a6, sh);        // its barriers also publish the list
+		// ---- scalars of saige_main.cpp:369-381, then Saddle_Prob_Fast
+		double xmu_c = 0, xsum_c = 0;
+#pragma unroll
+		for (int a = 0; a < K; a++) { xmu_c = fma(md.Xmu[a], c[a], xmu_c); xsum_c = fma(md.Xsum[a], c[a], xsum_c); }
+		const double m1 = (a6[0] - xmu_c) * inv;
+		const double Tstat = r.S * inv;
+		const double var2 = r.var2 / r.AC2, var1 = var2 * md.r;
+		const double qtilde = Tstat / sqrt(var1) * sqrt(var2) + m1;
+		const double sdev = qtilde - m1, qinv = -sdev + m1;
+		const double pn_in = d_pchisq1_upper(sdev * sdev / var2);
+		double pval;
+		bool converged = true;
+		if (fabs(qtilde - m1) / sqrt(var2) < 2.0) {
+			pval = pn_in;
+		} else {
+			const double nb = (xsum_c - a6[1]) * inv;
+			const double L = a6[2] + fmax(-nb, 0.0), U = a6[3] + fmin(-nb, 0.0);
+			const double mar = 1e-9 * (fabs(L) + fabs(U) + fabs(qtilde) + fabs(qinv));
+			if (!(qtilde < L - mar && qtilde > U + mar && qinv < L - mar && qinv > U + mar)) {
+				if (tid == 0) fb_dense[atomicAdd(&counters[2], 1)] = v;
+				continue;
+			}
+			const double NAmu = m1 - a6[4], NAsigma = var2 - a6[5];
+			RootState s1, s2;
+			root_begin(s1, qtilde, L, U);
+			root_begin(s2, qinv, L, U);
+			root_feed(s1, a6[4], a6[5], NAmu, NAsigma, 0.0, true);      // t = 0 needs no sweep (kern_spa3.h)
+			root_feed(s2, a6[4], a6[5], NAmu, NAsigma, 0.0, true);
+			// one sweep: K1, K2 (and Korg where wanted) of the active roots
+			auto sweep = [&](bool a1, bool a2, bool k1w, bool k2w, double t1, double t2, double (&sv)[6]) {
+#pragma unroll
+				for (int a = 0; a < 6; a++) sv[a] = 0;
+				for (int k0 = tid; k0 < nnz; k0 += 2 * SPA5_BLOCK) {
+					double2 gm[2];
+#pragma unroll
+					for (int j = 0; j < 2; j++) gm[j] = (k0 + j * SPA5_BLOCK < nnz) ? glist[k0 + j * SPA5_BLOCK] : make_double2(0.0, 0.5);   // g = 0 adds exactly 0
+#pragma unroll
+					for (int j = 0; j < 2; j++) {
+						if (a1) cgf_terms_rt(gm[j].x, gm[j].y, t1, k1w, sv[0], sv[1], sv[2]);
+						if (a2) cgf_terms_rt(gm[j].x, gm[j].y, t2, k2w, sv[3], sv[4], sv[5]);
+					}
+				}
+				block_sum<6, SPA5_BLOCK>(sv, sh);
+			};
+			while (s1.active || s2.active) {
+				const bool a1 = s1.active, a2 = s2.active, k1w = s1.want_k, k2w = s2.want_k;
+				double sv[6];
+				sweep(a1, a2, k1w, k2w, s1.tnew, s2.tnew, sv);
+				if (a1) root_feed(s1, sv[0], sv[1], NAmu, NAsigma, sv[2], k1w);
+				if (a2) root_feed(s2, sv[3], sv[4], NAmu, NAsigma, sv[5], k2w);
+			}
+			if (s1.converged && s2.converged) {
+				if (!(s1.k_ok && s2.k_ok)) {
+					// a search ended at a point evaluated without Korg (root_step's guess was wrong)
+					double sv[6];
+					sweep(!s1.k_ok, !s2.k_ok, true, true, s1.root, s2.root, sv);
+					if (!s1.k_ok) s1.Kcur = sv[2];
+					if (!s2.k_ok) s2.Kcur = sv[5];
+				}
+				const double p1 = lugannani_rice(s1.root, s1.Kcur, s1.K2cur, qtilde, NAmu, NAsigma);
+				const double p2 = lugannani_rice(s2.root, s2.Kcur, s2.K2cur, qinv, NAmu, NAsigma);
+				pval = fabs(p1) + fabs(p2);
+				if (pval != 0 && pn_in / pval > 1000) pval = pn_in;   // SPATest.cpp:368-371
+			} else {
+				pval = pn_in;
+				converged = false;
+			}
+		}
+		if (tid == 0) { const SpaRec rr = recs[v]; spa_write_row(rr, Tstat, var1, pval, converged, out8); }
+	}
+}

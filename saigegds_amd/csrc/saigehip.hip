@@ -63,6 +63,7 @@ static int fail(int code, const char *fmt, ...)
 #include "kern_spa.h"
 #include "kern_spa2.h"
 #include "kern_spa3.h"
+#include "kern_spa4.h"
 #include "kern_synth.h"
 #include "kern_grm.h"
 #include "kern_burden.h"
@@ -90,6 +91,13 @@ struct sgx_handle {
 	bool force_dense = false;         // test hook: every SPA variant takes the exact dense pass
 	bool fill_attr_set = false;       // spa3_fill's dynamic LDS size has been raised above 64 KiB
 	bool fill_ds_attr_set = false;    // same for spa3_fill_ds
+	// series SPA stage (kern_spa4.h)
+	double *seg4 = nullptr;           // [nseg][SPA4_NS][vcap4] partial sums of one round of flagged variants
+	int vcap4 = 0, nround4 = 0;
+	bool mom_attr_set = false;        // spa4_moments' dynamic LDS size has been raised above 64 KiB
+	uint8_t *scr5 = nullptr; int *cur5 = nullptr; int nwg5 = 0;   // spa5_kernel: per-workgroup lists, queue cursor
+	int spa_abl = 0;                  // timing experiments (wrong results)
+	bool force_exact = false;         // test hook: every SPA variant takes the exact exp/log kernels
 	// exact-integer MFMA score path (kern_score_mfma.h)
 	bool mf_ok = false;
 	MfTab mf[MF_MAXG]{};              // one limb table per column group
@@ -252,6 +260,9 @@ static int alloc_workspace(sgx_handle *h)
 	h->scratch_stride = 2 * (((size_t)N + 63) & ~(size_t)63);
 	HIPCHK(hipMalloc((void **)&h->scratch, h->scratch_stride * sizeof(double) * h->spa_grid));
 	if (!h->md.quant) {
+		h->nwg5 = h->n_cu * 2;
+		HIPCHK(hipMalloc((void **)&h->scr5, (size_t)h->nwg5 * spa5_wg_bytes(N)));
+		HIPCHK(hipMalloc((void **)&h->cur5, sizeof(int)));
 		// arena of (adj, mu) carrier lists shared by all flagged variants of a call
 		h->arena_cap = std::min<unsigned long long>(400000000ull, std::max<unsigned long long>(4000000ull, (unsigned long long)N * 1024ull));
 		HIPCHK(hipMalloc((void **)&h->arena, h->arena_cap * sizeof(double2)));
@@ -386,6 +397,16 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 	md.N = N; md.K = K; md.P = P; md.quant = quant;
 	md.tau0 = m->tau[0]; md.r = m->var_ratio;
 	sgx_set_thresholds(h, m->maf, m->mac, m->missing, m->spa_pval);
+	{
+		// series SPA stage: a quarter of the smallest convergence radius sqrt(logit(mu)^2 + pi^2)
+		// of log(1 - mu + mu e^x) over the model's fitted values (kern_spa4.h)
+		double l2min = INFINITY;
+		for (int i = 0; i < N; i++) {
+			const double mi = m->mu[i];
+			if (mi > 0 && mi < 1) { const double lg = std::log(mi / (1 - mi)); l2min = std::min(l2min, lg * lg); }
+		}
+		md.spa_xmax = std::isfinite(l2min) ? 0.25 * std::sqrt(l2min + M_PI * M_PI) : 0.0;
+	}
 	for (int a = 0; a < K * K; a++) md.XVX[a] = m->XVX[a];
 	for (int a = 0; a < K; a++) { md.S_a[a] = m->S_a[a]; md.Xmu[a] = (double)xmu[a]; md.Xsum[a] = (double)xsum[a]; }
 #define TRY(x) do { rc = (x); if (rc) { sgx_free(h); return rc; } } while (0)
@@ -421,7 +442,7 @@ extern "C" void sgx_free(sgx_handle *h)
 	}
 	(void)hipFree(h->fallback); (void)hipFree(h->fb_spa2); (void)hipFree(h->heads);
 	(void)hipFree(h->arena); (void)hipFree(h->cursor); (void)hipFree(h->segcnt); (void)hipFree(h->segpart); (void)hipFree(h->chunks); (void)hipFree(h->partial);
-	(void)hipFree(h->mf_acc);
+	(void)hipFree(h->mf_acc); (void)hipFree(h->seg4); (void)hipFree(h->scr5); (void)hipFree(h->cur5);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
 	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid); (void)hipFree(h->stage_pk); (void)hipFree(h->ds_part);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
@@ -448,11 +469,17 @@ static int ensure_recs(sgx_handle *h, size_t n)
 		if (h->segpart) HIPCHK(hipFree(h->segpart));
 		h->segcnt = nullptr; h->segpart = nullptr;
 		h->nseg = (h->md.N + spa3_seg(h->md.K) - 1) / spa3_seg(h->md.K);
+		if (h->seg4) HIPCHK(hipFree(h->seg4));
+		h->seg4 = nullptr;
+		h->vcap4 = (int)std::min<size_t>(n, 16384);       // flagged variants per round of the series SPA stage
+		h->nround4 = (int)((n + h->vcap4 - 1) / h->vcap4);
+		HIPCHK(hipMalloc((void **)&h->seg4, (size_t)h->nseg * SPA4_NS * h->vcap4 * sizeof(double)));
 		HIPCHK(hipMalloc((void **)&h->segcnt, n * (size_t)h->nseg * sizeof(int)));
 		HIPCHK(hipMalloc((void **)&h->segpart, n * (size_t)h->nseg * SPA3_NSEGP * sizeof(double)));
 		h->fb_spa2 = nullptr; h->heads = nullptr; h->chunks = nullptr; h->partial = nullptr;
 		h->chunk_cap = (int)std::min<unsigned long long>(0x7fffffffull, h->arena_cap / SPA3_CHUNK + n);
 		HIPCHK(hipMalloc((void **)&h->fb_spa2, n * sizeof(int)));
+
 		HIPCHK(hipMalloc((void **)&h->heads, n * sizeof(SpaHead)));
 		HIPCHK(hipMalloc((void **)&h->chunks, (size_t)h->chunk_cap * sizeof(ChunkDesc)));
 		HIPCHK(hipMalloc((void **)&h->partial, (size_t)h->chunk_cap * SPA3_NPART * sizeof(double)));
@@ -494,6 +521,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	hipStream_t st = h->stream;
 	HIPCHK(hipMemsetAsync(h->counters, 0, 8 * sizeof(int), st));
 	HIPCHK(hipMemsetAsync(h->cursor, 0, sizeof(unsigned long long), st));
+	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, sizeof(int), st));
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	const bool use_mf = (INPUT == IN_2BIT) && h->mf_ok && !h->force_v1;
 	if (use_mf) {
@@ -582,44 +610,27 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 #define CASE(KK)                                                                             \
 	case KK:                                                                                 \
 		if (INPUT == IN_2BIT) {                                                              \
-			const dim3 g256((unsigned)((M + 255) / 256));                                    \
-			const dim3 gchunk((unsigned)(h->n_cu * 8));                                      \
-			const dim3 gitem((unsigned)(h->n_cu * 16));                                      \
-			hipLaunchKernelGGL(spa3_count, gitem, dim3(256), 0, st, (const uint8_t *)rows,   \
-				row_bytes, md.N, h->nseg, spa3_seg(KK), h->recs, h->counters, h->segcnt);    \
-			hipLaunchKernelGGL((spa3_plan<KK>), g256, dim3(256), 0, st, md, h->nseg, h->recs,\
-				h->counters, h->cursor,                                                      \
-				(h->arena_limit ? std::min(h->arena_limit, h->arena_cap) : h->arena_cap),    \
-				h->segcnt, h->heads, h->fb_spa2, out8);      \
-			{                                                                                \
-				const size_t fl = (size_t)spa3_seg(KK) * (((KK) + 2) & ~1) * 8 + SPA3_FILL_WAVES * 1024 * 2; \
-				const int nslice = std::max(1, (2 * h->n_cu + h->nseg - 1) / h->nseg);       \
-				if (!h->fill_attr_set) {                                                     \
-					HIPCHK(hipFuncSetAttribute((const void *)spa3_fill<KK>,                  \
-						hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));               \
-					h->fill_attr_set = true;                                                 \
-				}                                                                            \
-				hipLaunchKernelGGL((spa3_fill<KK>), dim3((unsigned)std::min(h->nseg * nslice, 4 * h->n_cu)), \
-					dim3(WAVE * SPA3_FILL_WAVES), fl, st,                                    \
-					(const uint8_t *)rows, row_bytes, md, h->nseg, nslice, h->recs,          \
-					h->counters, h->segcnt, h->heads, h->arena, h->segpart);                 \
+			/* series SPA stage (kern_spa4.h): rounds of at most vcap4 flagged variants */   \
+			const size_t fl = spa4_lds_bytes(KK);                                            \
+			if (!h->mom_attr_set) {                                                          \
+				HIPCHK(hipFuncSetAttribute((const void *)spa4_moments<KK>,                   \
+					hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));                   \
+				h->mom_attr_set = true;                                                      \
 			}                                                                                \
-			hipLaunchKernelGGL((spa3_head<KK>), g256, dim3(256), 0, st, md, h->nseg,         \
-				h->recs, h->counters, h->segpart, h->heads, h->chunks, h->chunk_cap,         \
-				h->fallback, h->fb_spa2, out8, h->force_dense ? 1 : 0);                                              \
-			for (int lv = 0; lv < h->spa_levels; lv++) {                                     \
-				hipLaunchKernelGGL(spa3_pass, gchunk, dim3(SPA3_BLOCK), 0, st, h->counters,  \
-					h->chunks, h->heads, h->arena, h->partial);                              \
-				hipLaunchKernelGGL(spa3_advance, g256, dim3(256), 0, st, h->counters,        \
-					h->heads, h->partial);                                                   \
+			const int nround = (int)((M + h->vcap4 - 1) / h->vcap4);                         \
+			for (int rd = 0; rd < nround; rd++) {                                            \
+				hipLaunchKernelGGL((spa4_moments<KK>), dim3((unsigned)h->n_cu),                  \
+					dim3(WAVE * SPA4_WAVES), fl, st, (const uint8_t *)rows, row_bytes, md,   \
+					h->nseg, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl); \
+				hipLaunchKernelGGL((spa4_solve<KK>), dim3((unsigned)((h->vcap4 + 255) / 256)), dim3(256), 0, st, \
+					md, h->nseg, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4,     \
+					h->fallback, h->fb_spa2, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0); \
 			}                                                                                \
-			hipLaunchKernelGGL(spa3_korg, gchunk, dim3(SPA3_BLOCK), 0, st, h->counters,      \
-				h->chunks, h->heads, h->arena, h->partial);                                  \
-			hipLaunchKernelGGL(spa3_finish, g256, dim3(256), 0, st, h->counters, h->heads,   \
-				h->partial, h->recs, h->fb_spa2, out8);                                      \
-			hipLaunchKernelGGL((spa2_kernel<KK, PB>), sgrid, dim3(PB), 0, st,                \
-				(const uint8_t *)rows, row_bytes, md, h->recs, h->counters, 3, h->fb_spa2,   \
-				h->fallback, h->scratch, h->scratch_stride, out8);                           \
+			/* rare variants (large g t): exact exp/log sums, one workgroup per variant; then the  \
+			   exact dense g_pos / g_neg pass */                                             \
+			hipLaunchKernelGGL((spa5_kernel<KK>), dim3((unsigned)h->nwg5), dim3(SPA5_BLOCK), \
+				0, st, (const uint8_t *)rows, row_bytes, md, h->recs, h->counters,           \
+				h->fb_spa2, h->cur5, h->fallback, h->scr5, out8);                            \
 			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
 				row_bytes, md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
 				h->scratch_stride, out8);                                                    \
@@ -676,7 +687,8 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 #undef CASE
 		}
 		HIPCHK(hipGetLastError());
-		h->stats.spa_launches = (INPUT == IN_2BIT || !h->force_v1) ? (uint32_t)(8 + 2 * h->spa_levels) : 1u;
+		h->stats.spa_launches = (INPUT == IN_2BIT) ? (uint32_t)(2 * ((M + h->vcap4 - 1) / h->vcap4) + 3)
+			: (!h->force_v1 ? (uint32_t)(8 + 2 * h->spa_levels) : 1u);
 	}
 	HIPCHK(hipEventRecord(h->ev[2], st));
 	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -694,6 +706,8 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 	else if (n == "arena_limit") { if (value < 0) return fail(SGX_EINVAL, "arena_limit < 0"); h->arena_limit = (unsigned long long)value; }
 	else if (n == "score_v1") h->force_v1 = value != 0;
 	else if (n == "force_dense") h->force_dense = value != 0;
+	else if (n == "spa_exact") h->force_exact = value != 0;
+	else if (n == "spa_abl") h->spa_abl = (int)value;
 	else if (n == "lanes") {
 		if (value != 1 && value != 2) return fail(SGX_EINVAL, "lanes must be 1 or 2");
 		if (h->owner) return fail(SGX_EINVAL, "lanes: not on a twin");
@@ -706,7 +720,7 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 			for (int g = 0; g < MF_MAXG; g++) { t->mf[g] = h->mf[g]; t->mf_nbfv[g] = h->mf_nbfv[g]; }
 			t->dF = h->dF; t->dX = h->dX; t->dy = h->dy; t->dmu = h->dmu; t->dmu2 = h->dmu2; t->dXM = h->dXM; t->dFl = h->dFl;
 			t->shares_model = true; t->owner = h;
-			t->spa_levels = h->spa_levels; t->arena_limit = h->arena_limit; t->force_dense = h->force_dense; t->force_v1 = h->force_v1;
+			t->spa_levels = h->spa_levels; t->arena_limit = h->arena_limit; t->force_dense = h->force_dense; t->force_v1 = h->force_v1; t->force_exact = h->force_exact;
 			rc = set_dev(t);
 			if (!rc) rc = alloc_workspace(t);
 			if (rc) { sgx_free(t); return rc; }

@@ -189,8 +189,7 @@ def test_seqAssocGLMM_SPA_driver(grm1k, golden_bin, tmp_path):
 
 
 @pytest.mark.parametrize("option,value,counter", [
-    ("spa_levels", 1, "n_spa_slow"),      # stragglers finish in the per-workgroup kernel
-    ("arena_limit", 1000, "n_spa_slow"),  # carrier arena overflow
+    ("spa_exact", 1, "n_spa_slow"),       # every flagged variant through the exact exp/log kernel
     ("force_dense", 1, "n_spa_dense"),    # exact g_pos / g_neg pass (SPATest.cpp:328-332)
     ("score_v1", 1, None),                # gather score kernel instead of the MFMA path
 ])
@@ -200,7 +199,6 @@ def test_fallback_paths_give_identical_rows(option, value, counter):
     ref, ref_valid = _oracle(sm).scan_2bit(packed)
     with _scanner(sm) as sc:
         base, _ = sc.scan_2bit(packed)
-        assert sc.stats()["n_spa_slow"] == 0
         sc.set_option(option, value)
         out, valid = sc.scan_2bit(packed)
         st = sc.stats()
