@@ -95,7 +95,7 @@ def table_errors(out, ref, quant=False):
     with np.errstate(invalid="ignore", divide="ignore"):
         b, se = ref[:, 3], ref[:, 4]
         z = np.abs(b) / se
-        tol_b = REL_TOL * np.abs(b) + Z_FLOOR * se
+        tol_b = REL_TOL * np.abs(b) + Z_FLOOR * np.where(np.isfinite(se), se, 0.0)   # (SE is NaN where the reference's p is)
         tol_se = se * (REL_TOL + Z_FLOOR / np.maximum(z, 1e-300))
         errs = {"beta": np.abs(out[:, 3] - b) / tol_b, "SE": np.abs(out[:, 4] - se) / tol_se}
         for c, name in ((5, "pval"),) + (() if quant else ((6, "pval_noadj"),)):
