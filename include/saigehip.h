@@ -114,6 +114,13 @@ void sgx_free(sgx_handle *h);
 int  sgx_set_thresholds(sgx_handle *h, double maf, double mac, double missing,
 	double spa_pval);
 
+/* Fixed-point layout sgx_init chose for the exact-integer score stage: limbs[c] = bytes per entry of
+ * score column c in the order c' (K columns), e (K), s, w; 0 for a column that is derived instead
+ * of carried.  Columns of heavy-tailed covariates get more limbs than ordinary ones; n_groups = 0
+ * means the model's dynamic range exceeds what the fixed-point form holds and the scan uses the
+ * FP64 kernels. */
+int sgx_score_layout(sgx_handle *h, int32_t *limbs, int32_t n_limbs, int32_t *n_groups);
+
 /* Scan a block of variants held in HOST memory.  packed: n_variants rows of
  * bytes_per_variant bytes (>= ceil(N/4)).  out8: n_variants*8 doubles.
  * valid: n_variants bytes.  Synchronous. */

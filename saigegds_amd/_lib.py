@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libsaigehip.so")
 
 EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
-    "sgx_set_thresholds", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64", "sgx_burden_2bit", "sgx_geno_stats_2bit",
+    "sgx_set_thresholds", "sgx_score_layout", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64", "sgx_burden_2bit", "sgx_geno_stats_2bit",
     "sgx_sync", "sgx_get_stats", "sgx_get_stats_total", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
     "sgx_grm_init", "sgx_grm_init_dev", "sgx_grm_crossprod_dev", "sgx_grm_sync", "sgx_grm_free", "sgx_grm_diag", "sgx_grm_crossprod", "sgx_grm_pcg",
 )
@@ -95,6 +95,8 @@ def load():
     L.sgx_free.argtypes = [vp]
     L.sgx_set_thresholds.restype = C.c_int
     L.sgx_set_thresholds.argtypes = [vp, dp, dp, dp, dp]
+    L.sgx_score_layout.restype = C.c_int
+    L.sgx_score_layout.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
     L.sgx_scan_2bit.restype = C.c_int
     L.sgx_scan_2bit.argtypes = [vp, vp, sz, sz, vp, vp]
     L.sgx_scan_2bit_dev.restype = C.c_int
@@ -262,6 +264,14 @@ class Scanner:
 
     def set_option(self, name: str, value: int):
         check(self._L.sgx_set_option(self._h, name.encode(), int(value)))
+
+    def score_layout(self):
+        """(limb counts of the score columns c'(K), e(K), s, w; number of column groups, 0 = FP64 path)."""
+        p = 2 * self.k + 2
+        limbs = np.zeros(p, dtype=np.int32)
+        ng = C.c_int32(0)
+        check(self._L.sgx_score_layout(self._h, limbs.ctypes.data, p, C.byref(ng)))
+        return limbs, int(ng.value)
 
     def set_thresholds(self, maf, mac, missing, spa_pval):
         check(self._L.sgx_set_thresholds(self._h, maf, mac, missing, spa_pval))

@@ -334,13 +334,33 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		for (int k = 0; k < K; k++) order.push_back(K + k);
 		if (!ep.derive_c) for (int k = 0; k < K; k++) order.push_back(k);
 		for (int k = 0; k < K; k++) { ep.cgrp[k] = 0; ep.ccol[k] = 0; ep.climb[k] = 0; }
+		// Limb counts follow the measured dynamic range of each column.  A column is quantised against
+		// its largest entry, so an entry of typical size keeps 8 nl - 2 - log2(max / typical) bits: the
+		// reduced widths of kern_score_mfma.h "Limb counts" hold for covariates whose largest value is
+		// a few times the typical one (max / mean|.| = 5.6 for a standard normal column at N = 430 000)
+		// and are widened for heavy-tailed ones; beyond 2^22 no width is enough and the model takes the
+		// FP64 gather kernels instead of the MFMA path.
+		bool range_ok = true;
+		auto limbs_for = [&](int c) -> int {
+			if (c == CW && quant) return 1;
+			long double sum = 0; double mx = 0;
+			for (int i = 0; i < N; i++) { const double a = std::fabs(F[(size_t)i * P + c]); sum += a; mx = std::max(mx, a); }
+			const double range = sum > 0 ? mx / (double)(sum / N) : 1.0;
+			if (!(range <= 4194304.0)) range_ok = false;
+			int nl = c >= 2 * K ? MF_NLIMB : (c >= K ? MF_LIMB_E : MF_LIMB_A);
+			if (range > 64.0) nl = std::max(nl, MF_LIMB_E);
+			if (range > 16384.0) nl = MF_NLIMB;
+			return nl;
+		};
 		int g = 0, used = 1, glimbs[MF_MAXG] = {0};   // group 0: one column for the constant 1
 		for (int c : order) {
-			const int nl = c == CW ? (quant ? 1 : MF_NLIMB) : c >= 2 * K ? MF_NLIMB : (c >= K ? MF_LIMB_E : MF_LIMB_A);
+			const int nl = limbs_for(c);
 			if (used + nl > MF_GLIMBS) { glimbs[g] = used; g++; used = 0; }
+			if (g >= MF_MAXG) { range_ok = false; break; }
 			ep.cgrp[c] = (unsigned char)g; ep.ccol[c] = (unsigned char)(used - (g == 0 ? 1 : 0)); ep.climb[c] = (unsigned char)nl;
 			used += nl;
 		}
+		if (range_ok) {
 		glimbs[g] = used;
 		ep.ngroups = g + 1;
 		int off = 0;
@@ -392,6 +412,7 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 			at(0, i, ep.col_b1 + ep.climb[CW]) = 1;
 		}
 		h->mf_ok = true;
+		}
 	}
 	DevModel &md = h->md;
 	md.N = N; md.K = K; md.P = P; md.quant = quant;
@@ -427,6 +448,16 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 #undef TRY
 	{ const char *e = getenv("SAIGEHIP_SCORE_V1"); h->force_v1 = e && e[0] == '1'; }
 	*out = h;
+	return SGX_OK;
+}
+
+// limb counts of the fixed-point score columns [c' (K), e (K), s, w] and the number of column
+// groups; 0 groups = the model takes the FP64 gather kernels
+extern "C" int sgx_score_layout(sgx_handle *h, int32_t *limbs, int32_t n_limbs, int32_t *n_groups)
+{
+	if (!h || !n_groups) return fail(SGX_EINVAL, "sgx_score_layout: NULL argument");
+	*n_groups = h->mf_ok ? h->mfe.ngroups : 0;
+	for (int c = 0; limbs && c < n_limbs; c++) limbs[c] = (h->mf_ok && c < h->md.P) ? h->mfe.climb[c] : 0;
 	return SGX_OK;
 }
 

@@ -80,14 +80,19 @@ def _irls_logistic(X, y, iters=50):
 
 
 def synth_null_model(n_samp: int, trait: str = "binary", prevalence: float = 0.10,
-                     n_cov: int = 3, seed: int = 20260, var_ratio: float | None = None) -> NullModel:
+                     n_cov: int = 3, seed: int = 20260, var_ratio: float | None = None,
+                     outlier: float = 0.0) -> NullModel:
     """Model object with the structure SPAtest/seqFitNullGLMM_SPA would produce
     (tau = (1, 0): the GLMM fitted values equal the no-K glm fit)."""
     rng = np.random.default_rng(seed)
     X = np.ones((n_samp, n_cov))
     for k in range(1, n_cov):
         X[:, k] = rng.standard_normal(n_samp) if k % 2 == 1 else rng.integers(0, 2, n_samp)
+    if outlier and n_cov > 1:
+        X[7 % n_samp, 1] = outlier          # a heavy-tailed covariate: one sample far outside the column's scale
     bcov = np.full(n_cov - 1, 0.5)
+    if outlier:
+        bcov[0] = 0.0                       # (no effect on the trait: the fit stays well-posed)
     if trait == "binary":
         lo, hi = -20.0, 20.0
         lin = X[:, 1:] @ bcov

@@ -93,6 +93,31 @@ def test_covariate_counts(k):
     assert_table_close(out, valid, ref, ref_valid, what=f"K={k}")
 
 
+@pytest.mark.parametrize("trait", ["binary", "quantitative"])
+def test_heavy_tailed_covariate_widens_limbs(trait):
+    """A covariate with one sample 10^4 x the column scale (K = 5): sgx_init measures the dynamic
+    range of every fixed-point column and widens the affected ones; results stay inside 1e-10."""
+    from saigegds_amd import synth
+    from saigegds_amd.nullmod import init_nullmod
+    n, m = 5000, 1200
+    thr = synth.variant_thresholds(0, m, 5, log10_maf=(-2.5, -0.3), flip_frac=0.3, miss_rate=1e-2)
+    packed = synth.synth_packed(n, 0, m, 5, thr)
+    layouts = {}
+    for outlier in (0.0, 1e4):
+        mod = synth.synth_null_model(n, trait, 0.1, n_cov=5, seed=77, outlier=outlier)
+        sm = init_nullmod(mod, np.arange(n), float("nan"), 10, 0.1, 0.05, float(mod.var_ratio[0]))
+        ref, ref_valid = _oracle(sm).scan_2bit(packed)
+        with _scanner(sm) as sc:
+            layouts[outlier] = sc.score_layout()
+            out, valid = sc.scan_2bit(packed)
+        assert_table_close(out, valid, ref, ref_valid, quant=sm.quant, what=f"{trait} outlier={outlier}")
+    plain, wide = layouts[0.0], layouts[1e4]
+    assert plain[1] >= 1 and wide[1] >= 1                      # both on the exact-integer path
+    assert (wide[0] >= plain[0]).all(), (plain, wide)
+    if trait == "binary":                                       # the 5-limb c' column of the outlier covariate
+        assert wide[0].sum() > plain[0].sum(), (plain, wide)
+
+
 def test_dosage_inputs(grm1k, model_bin):
     """RAW and REAL branches of get_ds (saige_main.cpp:171-183)."""
     from saigegds_amd.gds import unpack_dosage_2bit
