@@ -20,6 +20,7 @@ struct DevModel {
 	double Xmu[KMAX];   // X' mu
 	double Xsum[KMAX];  // X' 1
 	double spa_xmax;    // series SPA stage (kern_spa4.h): largest max_i |g_i t| it accepts
+	double Xabs[KMAX];  // max_i |X[i,k]|
 };
 
 // a variant handed from the score stage to the SPA stage
@@ -27,7 +28,7 @@ struct SpaRec {
 	int j;            // variant index in the block
 	int minus;        // AF > 0.5
 	int nnz;          // carriers: samples whose (imputed, flipped) dosage is non-zero
-	int has_gmu;      // sum_gmu is valid (MFMA score path)
+	int has_gmu;      // (unused)
 	double lut[4];    // dosage value per 2-bit code after impute + flip
 	double AC2;       // allele count of the tested (minor) allele
 	double p_noadj;
@@ -274,6 +275,36 @@ __device__ __forceinline__ VarHead make_head(const DevModel &md, double AC, int 
 	return h;
 }
 
+// Series SPA stage (kern_spa4.h): a flagged variant starts in tier A (short series) while the predicted
+// max_i |g_i t| is small: t ~ 1.5 x the first Newton point, |g_i| <= (2 + sum_k |c'_k| max_i |X_ik|) / sqrt(AC2).
+#define SPA4_TIER_X 0.45
+#define SPA4_EXACT_X 1.3         /* beyond this the series is not tried: straight to the exact kernel */
+__device__ __forceinline__ int spa_tier(const DevModel &md, const SpaRec &r)
+{
+	double bmax = 0;
+	for (int k = 0; k < md.K; k++) bmax += fabs(r.c[k]) * md.Xabs[k];
+	const double t1 = fabs(r.S) * sqrt(r.AC2) / (sqrt(md.r) * r.var2);
+	const double x = 1.5 * t1 * (2.0 + bmax) / sqrt(r.AC2);
+	return (x <= SPA4_TIER_X) ? 0 : ((x <= SPA4_EXACT_X) ? 1 : 2);
+}
+
+// Record of a flagged variant into recs[]: tier A from slot 0 upwards (counters[0]), tier B from slot
+// btop - 1 downwards (counters[7]), the variants that go straight to the exact kernel from slot btop
+// upwards (counters[5]; their indices also onto the exact kernel's list fb_exact, counters[3]).
+// btop = 0: one range only.
+__device__ __forceinline__ void spa_push(const DevModel &md, SpaRec *recs, int *counters, int btop, int *fb_exact, const SpaRec &r)
+{
+	const int tier = btop > 0 ? spa_tier(md, r) : 0;
+	int slot;
+	if (tier == 2) {
+		slot = btop + atomicAdd(&counters[5], 1);
+		fb_exact[atomicAdd(&counters[3], 1)] = slot;
+	} else {
+		slot = tier ? btop - 1 - atomicAdd(&counters[7], 1) : atomicAdd(&counters[0], 1);
+	}
+	recs[slot] = r;
+}
+
 // Score epilogue: from the P reduced sums to the output row; returns 1 when the
 // variant has to go through the SPA stage.
 //   binary saige_main.cpp:313-356, quantitative :225-272
@@ -308,9 +339,26 @@ __device__ int score_epilogue(const DevModel &md, const VarHead &h, const double
 	if (!md.quant) {
 		const int converged = isfinite(pval);
 		if (converged && pval <= md.thr_spa) {
+			out[6] = pval;
+			// Saddle_Prob_Fast's first test (SPATest.cpp:319-321): |q - m1| / sqrt(var1) < cutoff = 2
+			// returns pval_noadj.  With q~ - m1 = Tstat / sqrt(var1) * sqrt(var2) (saige_main.cpp:381)
+			// it needs nothing but the score stage's sums -- no carrier pass for the variants between
+			// |z| = 1.96 and 2 (9 % of the flagged ones).
+			const double AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
+			const double Tstat = S / sqrt(AC2), v2 = var2 / AC2, v1 = v2 * md.r;
+			const double sdev = Tstat / sqrt(v1) * sqrt(v2);
+			if (fabs(sdev) / sqrt(v2) < 2.0) {
+				const double pn = d_pchisq1_upper(sdev * sdev / v2);
+				double bs = (Tstat / v1) / sqrt(AC2);          // saige_main.cpp:392
+				if (h.minus) bs = -bs;
+				out[3] = bs;
+				out[4] = fabs(bs / d_qnorm(pn / 2));
+				out[5] = pn;
+				out[7] = 1.0;
+				return 0;
+			}
 			for (int a = 0; a < K; a++) c_out[a] = c[a];
 			*p_noadj_out = pval; *S_out = S; *var2_out = var2;
-			out[6] = pval;
 			return 1;
 		}
 		out[6] = pval; out[7] = converged ? 1.0 : 0.0;

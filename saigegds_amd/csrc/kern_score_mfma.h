@@ -313,7 +313,7 @@ __device__ __forceinline__ HiLo mf_limbs(const int *a, int nl = MF_NLIMB)
 template <int K>
 __global__ void __launch_bounds__(256)
 score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf,
-	SpaRec *__restrict__ recs, int *__restrict__ counters, double *__restrict__ out8,
+	SpaRec *__restrict__ recs, int *__restrict__ counters, int btop, int *__restrict__ fb_exact, double *__restrict__ out8,
 	uint8_t *__restrict__ valid)
 {
 	constexpr int P = 2 * K + 2, CW = P - 1;     // score columns c' (K), e (K), s, w; column CW carries G^2
@@ -374,14 +374,13 @@ score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf
 	double cbuf[KMAX], pn, Ssc, v2sc;
 	valid[j] = 1;
 	if (score_epilogue(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
-		const int slot = atomicAdd(&counters[0], 1);
 		SpaRec rr;
 		rr.j = j; rr.minus = h.minus; rr.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
 		rr.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); rr.has_gmu = 0; rr.sum_gmu = 0;   // m1: SPA stage, carrier sums
 		rr.p_noadj = pn; rr.S = Ssc; rr.var2 = v2sc; rr.tscale = spa_tscale(Ssc, v2sc, rr.AC2, md.r);
 		for (int k = 0; k < 4; k++) rr.lut[k] = h.lut[k];
 		for (int k = 0; k < KMAX; k++) rr.c[k] = (k < md.K) ? cbuf[k] : 0.0;
-		recs[slot] = rr;
+		spa_push(md, recs, counters, btop, fb_exact, rr);
 	}
 	atomicAdd(&counters[1], 1);
 }

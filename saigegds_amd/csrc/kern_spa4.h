@@ -39,24 +39,31 @@
 //                 kern_spa2.h, fed from the series), tail probabilities, SE, the output row
 
 #define SPA4_WAVES 8
-#define SPA4_NS (SPA4_NC + 5)    /* partial sums per (variant, segment) */
-#define SPA4_TAIL_TOL 1e-13
+#define SPA4_NCA 12              /* cumulants carried for the variants of tier A (small g t: most carriers) */
+#define SPA4_NCB SPA4_NC         /* ... of tier B */
+#define SPA4_NSMAX (SPA4_NC + 5) /* partial sums per (variant, segment) of the wider tier */
+// The last two terms of the K2 series may be this fraction of its sum.  K2 enters the tail
+// probability only through log(v/w)/w: measured over the bench workload the p-value moves by less
+// than 1/80 of that fraction (tests/diagnostics/cumulant_proto.py), i.e. stays under ~1e-12.
+#define SPA4_TAIL_TOL 1e-10
 
 // T_n = y^n c_n(mu)/n! for n = 3..NC added to acc[n - 3];  y = adj * ts.
 // The polynomials in u are summed over explicit powers of u (one multiply-add per coefficient with
 // the coefficient as the constant operand), not by Horner's rule, whose running value would need a
 // register copy of every coefficient first.
+template <int NC>
 __device__ __forceinline__ void spa4_cum_terms(double y, double u, double d, double *acc)
 {
-	double up[SPA4_CDEG];          // u^k
+	constexpr int ND = (NC - 2) / 2 + 1;          // powers of u needed
+	double up[ND];                 // u^k
 	up[0] = 1.0; up[1] = u;
 #pragma unroll
-	for (int k = 2; k < SPA4_CDEG; k++) up[k] = up[k - 1] * u;
+	for (int k = 2; k < ND; k++) up[k] = up[k - 1] * u;
 	const double y2 = y * y;
 	double pe = y2 * u;            // y^n u      (even n, starting at n = 2)
 	double po = pe * y * d;        // y^n u d    (odd n, starting at n = 3)
 #pragma unroll
-	for (int n = 3; n <= SPA4_NC; n++) {
+	for (int n = 3; n <= NC; n++) {
 		const int deg = (n - 2) / 2;      // degree of the polynomial in u
 		double b = SPA4_CUM[n][0];
 #pragma unroll
@@ -72,34 +79,39 @@ __device__ __forceinline__ void spa4_cum_terms(double y, double u, double d, dou
 }
 
 // Sum V doubles per lane over the wave with ~V shuffles instead of 6 V: at every step a lane keeps
-// half of its values and hands the other half to its partner (xor 32, 16, .. 2), the last step adds
-// the two lanes that hold the same value.  Afterwards v[0] of lane l is the total of value
-//   idx = 12 b5 + 6 b4 + 3 b3 + 2 b2 + b1   (b_k = bit k of l; idx with b2 = b1 = 1 is padding)
-// for V <= 24.  The tree is fixed, so the result does not depend on scheduling.
+// half of its values and hands the other half to its partner (xor 32, 16, ..), the last steps add
+// the lanes that hold the same value.  Afterwards x[0] of lane l is the total of value idx (returned;
+// idx >= V: padding).  The tree is fixed, so the result does not depend on scheduling.
+//   V in 17..24: halves 24 -> 12 -> 6 -> 3 (padded to 4) -> 2 -> 1, idx = 12 b5 + 6 b4 + 3 b3 + 2 b2 + b1
+//                (b2 = b1 = 1 is padding)
+//   V in  9..16: halves 16 -> 8 -> 4 -> 2 -> 1,                     idx = 8 b5 + 4 b4 + 2 b3 + b2
 template <int V>
-__device__ __forceinline__ int wave_reduce_scatter24(double (&x)[V], int lane)
+__device__ __forceinline__ int wave_reduce_scatter(double (&x)[V], int lane)
 {
-	static_assert(V <= 24 && V > 18, "written for 19..24 values");
+	static_assert(V <= 24 && V > 8, "written for 9..24 values");
+	constexpr bool WIDE = V > 16;
+	constexpr int NST = WIDE ? 5 : 4;
 	int idx = 0;
 #pragma unroll
-	for (int st = 0; st < 5; st++) {
-		const int o = 32 >> st;                                  // 32 16 8 4 2
-		const int n = st == 0 ? 24 : st == 1 ? 12 : st == 2 ? 6 : st == 3 ? 4 : 2;   // values held (3 padded to 4)
+	for (int st = 0; st < NST; st++) {
+		const int o = 32 >> st;
+		const int n = WIDE ? (st == 0 ? 24 : st == 1 ? 12 : st == 2 ? 6 : st == 3 ? 4 : 2) : (16 >> st);   // values held
 		const int half = n / 2;
 		const bool up = (lane & o) != 0;
 #pragma unroll
 		for (int i = 0; i < half; i++) {
-			// slots past the V values of the first step, and the pad slot of the fourth, hold zero
-			const bool hi_real = st == 0 ? (i + half < V) : !(st == 3 && i + half == 3);
+			// slots past the V values of the first step, and the pad slot of the wide form's fourth, hold zero
+			const bool hi_real = st == 0 ? (i + half < V) : !(WIDE && st == 3 && i + half == 3);
 			const double xh = hi_real ? x[i + half] : 0.0;
 			const double send = up ? x[i] : xh;
 			const double keep = up ? xh : x[i];
 			x[i] = keep + __shfl_xor(send, o, WAVE);
 		}
-		idx += up ? (st == 0 ? 12 : st == 1 ? 6 : st == 2 ? 3 : st == 3 ? 2 : 1) : 0;
+		idx += up ? (WIDE ? (st == 0 ? 12 : st == 1 ? 6 : st == 2 ? 3 : st == 3 ? 2 : 1) : (8 >> st)) : 0;
 	}
 	x[0] += __shfl_xor(x[0], 1, WAVE);
-	return idx;
+	if (!WIDE) x[0] += __shfl_xor(x[0], 2, WAVE);
+	return (WIDE && (lane & 6) == 6) ? 24 : idx;
 }
 
 #define SPA4_VPER 128            /* flagged variants whose parameters a workgroup holds in LDS at a time */
@@ -110,15 +122,19 @@ __host__ __device__ constexpr size_t spa4_lds_bytes(int K)
 	return (size_t)spa3_seg(K) * ((K + 2) & ~1) * 8 + (size_t)SPA4_VPER * (8 + 8 * (K + 6));
 }
 
+// The flagged variants of a call sit in recs[] in two ranges: tier A from slot 0 upwards (counters[0]
+// of them), tier B from slot btop - 1 downwards (counters[7]); rec index of the v-th of a tier:
+__device__ __forceinline__ int spa4_rec(int tier, int btop, int v) { return tier ? btop - 1 - v : v; }
+
 // One workgroup per CU.  Item = (sample segment, slice of SPA4_VPER flagged variants): the segment's X
 // rows and mu and the slice's parameters are staged in LDS; one wave per variant, a lane owns SEG/64
 // consecutive samples of the segment and walks its carriers in lock step with the other lanes.
-template <int K>
+template <int K, int NC>
 __global__ void __launch_bounds__(WAVE * SPA4_WAVES)
-spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg, int v0, int vcap,
+spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg, int tier, int btop, int v0, int vcap,
 	const SpaRec *__restrict__ recs, const int *__restrict__ counters, double *__restrict__ segpart, int abl)
 {
-	constexpr int SEG = spa3_seg(K), KP = (K + 2) & ~1;
+	constexpr int SEG = spa3_seg(K), KP = (K + 2) & ~1, NS = NC + 5;
 	constexpr int LDW = SEG / 16 / WAVE > 0 ? SEG / 16 / WAVE : 1;     // dwords (of 16 samples) per lane
 	constexpr int NLANE = SEG / 16 / LDW;                              // lanes that own samples
 	static_assert(LDW == 1 || LDW == 2 || LDW == 4, "segment sizes 512..4096");
@@ -127,7 +143,7 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 	double *pd = tab + (size_t)SEG * KP;                                                  // [K + 6][VPER]: inv, ts, c[K], lut[4]
 	int *pj = reinterpret_cast<int *>(pd + (size_t)(K + 6) * SPA4_VPER);                 // [VPER] row, [VPER] flip mask
 	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-	const int nflag = min(counters[0] - v0, vcap);
+	const int nflag = min(counters[tier ? 7 : 0] - v0, vcap);
 	if (nflag <= 0) return;
 	// the (segment, slice) items in segment-major order, an equal contiguous share per workgroup:
 	// a workgroup restages the table only when its range crosses into the next segment
@@ -163,7 +179,7 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 			samp0 = seg * SEG + lane * LDW * 16;
 		}
 		for (int i = tid; i < nv; i += WAVE * SPA4_WAVES) {
-			const SpaRec &r = recs[v0 + vb + i];
+			const SpaRec &r = recs[spa4_rec(tier, btop, v0 + vb + i)];
 			pj[i] = r.j;
 			pj[SPA4_VPER + i] = r.minus ? (int)0xAAAAAAAAu : 0;
 			pd[i] = 1 / sqrt(r.AC2);
@@ -190,9 +206,9 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 			const double *lut = pd + (2 + K) * SPA4_VPER + vl;       // dosage of code k at lut[k * VPER]
 			// 0 sum mu*G, 1 sum b, 2 sum max(adj,0), 3 sum min(adj,0), 4 sum adj*mu, 5 sum adj^2 mu(1-mu),
 			// 6.. kappa'_3..NC; max |adj| apart
-			double acc[SPA4_NS - 1], gmax = 0;
+			double acc[NS - 1], gmax = 0;
 #pragma unroll
-			for (int a = 0; a < SPA4_NS - 1; a++) acc[a] = 0;
+			for (int a = 0; a < NS - 1; a++) acc[a] = 0;
 			// carrier masks: bit b of lo -> dword (b & 1), sample b >> 1 of it; hi the same for dwords 2, 3
 			const uint32_t wd0 = wv.x, wd1 = wv.y, wd2 = wv.z, wd3 = wv.w;
 			auto nzm = [&](uint32_t w, int k) -> uint32_t {
@@ -231,7 +247,7 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 				acc[4] = fma(adj, mui, acc[4]);
 				acc[5] = fma(adj * adj, u, acc[5]);
 				gmax = fmax(gmax, fabs(adj));
-				if (!(abl & 1)) spa4_cum_terms(adj * ts, u, 1 - 2 * mui, &acc[6]);
+				if (!(abl & 1)) spa4_cum_terms<NC>(adj * ts, u, 1 - 2 * mui, &acc[6]);
 			};
 			Car ca, cb;
 			fetch(ca);
@@ -243,32 +259,33 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 				fetch(ca);
 				if (cb.ok) work(cb);
 			}
-			if (abl & 32) { if (lane == 0) segpart[(size_t)seg * SPA4_NS * vcap + (vb + vl)] = acc[0] + gmax; continue; }
-			const int idx = wave_reduce_scatter24(acc, lane);
+			const int idx = wave_reduce_scatter(acc, lane);
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o, WAVE));
-			const size_t base = (size_t)seg * SPA4_NS * vcap + (vb + vl);
-			if (!(lane & 1) && (lane & 6) != 6 && idx < SPA4_NS - 1) segpart[base + (size_t)idx * vcap] = acc[0];
-			if (lane == 1) segpart[base + (size_t)(SPA4_NS - 1) * vcap] = gmax;
+			const size_t base = (size_t)seg * NS * vcap + (vb + vl);
+			if (!(lane & (NS - 1 > 16 ? 1 : 3)) && idx < NS - 1) segpart[base + (size_t)idx * vcap] = acc[0];
+			if (lane == 1) segpart[base + (size_t)(NS - 1) * vcap] = gmax;
 		}
 	}
 }
 
 // the carrier series of one variant
+template <int NC>
 struct Spa4Series {
 	double k1, k2;               // kappa_1 = sum g mu, kappa_2 = sum g^2 mu (1 - mu)
-	double kp[SPA4_NC - 2];      // kappa'_n = kappa_n ts^n / n!, n = 3..NC
+	double kp[NC - 2];           // kappa'_n = kappa_n ts^n / n!, n = 3..NC
 	double ts, gmax;
 };
 
 // K1 (without "- q"), K2 and Korg sums at t (SPATest.cpp:49,64,79); false when the series cannot
 // be trusted there
-__device__ __forceinline__ bool spa4_eval(const Spa4Series &S, double xmax, double t, double &K1s, double &K2s, double &K0s)
+template <int NC>
+__device__ __forceinline__ bool spa4_eval(const Spa4Series<NC> &S, double xmax, double t, double &K1s, double &K2s, double &K0s)
 {
 	const double its = 1 / S.ts, tau = t * its;       // ts is a power of two
 	double p0 = 0, p1 = 0, p2 = 0;
 #pragma unroll
-	for (int n = SPA4_NC; n >= 3; n--) {
+	for (int n = NC; n >= 3; n--) {
 		const double kn = S.kp[n - 3];
 		p0 = fma(p0, tau, kn);
 		p1 = fma(p1, tau, (double)n * kn);
@@ -279,17 +296,17 @@ __device__ __forceinline__ bool spa4_eval(const Spa4Series &S, double xmax, doub
 	K1s = S.k1 + fma(t, S.k2, p1 * tau2 * its);
 	K2s = fma(p2 * tau, its * its, S.k2);
 	// the last two terms of the K2 series, tau^(NC-2) and tau^(NC-3)
-	double tp = tau2;                   // tau^2
-	tp *= tp;                           // tau^4
-	double t13 = tp * tp * tp * tau;    // tau^13
-	static_assert(SPA4_NC == 16, "tail powers are written for NC = 16");
-	const double tail = (fabs((double)(SPA4_NC * (SPA4_NC - 1)) * S.kp[SPA4_NC - 3] * t13 * tau) +
-		fabs((double)((SPA4_NC - 1) * (SPA4_NC - 2)) * S.kp[SPA4_NC - 4] * t13)) * its * its;
+	double tp = tau;                    // tau^(NC-3)
+#pragma unroll
+	for (int k = 1; k < NC - 3; k++) tp *= tau;
+	const double tail = (fabs((double)(NC * (NC - 1)) * S.kp[NC - 3] * tp * tau) +
+		fabs((double)((NC - 1) * (NC - 2)) * S.kp[NC - 4] * tp)) * its * its;
 	return S.gmax * fabs(t) <= xmax && tail <= SPA4_TAIL_TOL * fabs(K2s) && isfinite(K2s);
 }
 
-// getroot_K1_fast (SPATest.cpp:139-184) on the series; false = leave to the exact kernels
-__device__ __forceinline__ bool spa4_root(const Spa4Series &S, double xmax, double q, double NAmu, double NAsigma, RootState &s)
+// getroot_K1_fast (SPATest.cpp:139-184) on the series; false = the series does not hold somewhere
+template <int NC>
+__device__ __forceinline__ bool spa4_root(const Spa4Series<NC> &S, double xmax, double q, double NAmu, double NAsigma, RootState &s)
 {
 	root_begin(s, q, 0, 0);
 	root_feed(s, S.k1, S.k2, NAmu, NAsigma, 0.0, true);      // t = 0: K1 = kappa_1, K2 = kappa_2, Korg = 0
@@ -301,25 +318,37 @@ __device__ __forceinline__ bool spa4_root(const Spa4Series &S, double xmax, doub
 	return true;
 }
 
-// one thread per flagged variant of the round [v0, v0 + vcap)
-template <int K>
+// one wave per flagged variant of the tier's round [v0, v0 + vcap).  A tier-A variant whose series
+// is too short is handed to tier B (a copy of its record at the end of that range); from tier B it goes
+// to the exact kernels.
+template <int K, int NC>
 __global__ void __launch_bounds__(256)
-spa4_solve(DevModel md, int nseg, int v0, int vcap, const SpaRec *__restrict__ recs, int *__restrict__ counters,
+spa4_solve(DevModel md, int nseg, int tier, int btop, int v0, int vcap, SpaRec *__restrict__ recs, int *__restrict__ counters,
 	const double *__restrict__ segpart, int *__restrict__ fb_dense, int *__restrict__ fb_spa2,
 	double *__restrict__ out8, int force_dense, int force_exact)
 {
-	const int v = blockIdx.x * blockDim.x + threadIdx.x;
-	if (v >= min(counters[0] - v0, vcap)) return;
-	const SpaRec r = recs[v0 + v];
-	double a[SPA4_NS];
+	constexpr int NS = NC + 5;
+	// one wave per variant: the lanes share the segments' partial sums (fixed tree), then all of
+	// them run the scalar part on identical values and lane 0 writes
+	const int lane = threadIdx.x & (WAVE - 1);
+	const int v = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
+	if (v >= min(counters[tier ? 7 : 0] - v0, vcap)) return;
+	const int ri = spa4_rec(tier, btop, v0 + v);
+	const SpaRec r = recs[ri];
+	double a[NS];
 #pragma unroll
-	for (int x = 0; x < SPA4_NS; x++) a[x] = 0;
-	for (int s = 0; s < nseg; s++) {
-		const double *p = segpart + (size_t)s * SPA4_NS * vcap + v;
+	for (int x = 0; x < NS; x++) a[x] = 0;
+	for (int s = lane; s < nseg; s += WAVE) {
+		const double *p = segpart + (size_t)s * NS * vcap + v;
 #pragma unroll
-		for (int x = 0; x < SPA4_NS - 1; x++) a[x] += p[(size_t)x * vcap];
-		a[SPA4_NS - 1] = fmax(a[SPA4_NS - 1], p[(size_t)(SPA4_NS - 1) * vcap]);
+		for (int x = 0; x < NS - 1; x++) a[x] += p[(size_t)x * vcap];
+		a[NS - 1] = fmax(a[NS - 1], p[(size_t)(NS - 1) * vcap]);
 	}
+#pragma unroll
+	for (int x = 0; x < NS - 1; x++) a[x] = wave_sum(a[x]);
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) a[NS - 1] = fmax(a[NS - 1], __shfl_xor(a[NS - 1], o, WAVE));
+	if (lane != 0) return;
 	// scalars of saige_main.cpp:369-381
 	const double inv = 1 / sqrt(r.AC2);
 	double xmu_c = 0, xsum_c = 0;
@@ -331,8 +360,8 @@ spa4_solve(DevModel md, int nseg, int v0, int vcap, const SpaRec *__restrict__ r
 	const double qtilde = Tstat / sqrt(var1) * sqrt(var2) + m1;   // :381
 	const double sdev = qtilde - m1, qinv = -sdev + m1;
 	const double pn_in = d_pchisq1_upper(sdev * sdev / var2);
-	if (fabs(qtilde - m1) / sqrt(var2) < 2.0) {           // SPATest.cpp:319-321
-		spa_write_row(r, Tstat, var1, pn_in, true, out8);
+	if (fabs(qtilde - m1) / sqrt(var2) < 2.0) {           // SPATest.cpp:319-321 (the score epilogue takes
+		spa_write_row(r, Tstat, var1, pn_in, true, out8);  // these out already; kept for rounding at the edge)
 		return;
 	}
 	// g_pos / g_neg bound test (kern_spa2.h)
@@ -340,18 +369,24 @@ spa4_solve(DevModel md, int nseg, int v0, int vcap, const SpaRec *__restrict__ r
 	const double L = a[2] + fmax(-nb, 0.0), U = a[3] + fmin(-nb, 0.0);
 	const double mar = 1e-9 * (fabs(L) + fabs(U) + fabs(qtilde) + fabs(qinv));
 	if (force_dense || !(qtilde < L - mar && qtilde > U + mar && qinv < L - mar && qinv > U + mar)) {
-		fb_dense[atomicAdd(&counters[2], 1)] = v0 + v;
+		fb_dense[atomicAdd(&counters[2], 1)] = ri;
 		return;
 	}
-	Spa4Series S;
-	S.k1 = a[4]; S.k2 = a[5]; S.ts = r.tscale; S.gmax = a[SPA4_NS - 1];
+	Spa4Series<NC> S;
+	S.k1 = a[4]; S.k2 = a[5]; S.ts = r.tscale; S.gmax = a[NS - 1];
 #pragma unroll
-	for (int x = 0; x < SPA4_NC - 2; x++) S.kp[x] = a[6 + x];
+	for (int x = 0; x < NC - 2; x++) S.kp[x] = a[6 + x];
 	const double NAmu = m1 - a[4], NAsigma = var2 - a[5];
 	RootState s1, s2;
 	if (force_exact || !spa4_root(S, md.spa_xmax, qtilde, NAmu, NAsigma, s1) ||
 		!spa4_root(S, md.spa_xmax, qinv, NAmu, NAsigma, s2)) {
-		fb_spa2[atomicAdd(&counters[3], 1)] = v0 + v;
+		if (tier == 0 && !force_exact) {
+			const int slot = atomicAdd(&counters[7], 1);       // on to the longer series
+			atomicAdd(&counters[6], 1);
+			recs[btop - 1 - slot] = r;
+		} else {
+			fb_spa2[atomicAdd(&counters[3], 1)] = ri;
+		}
 		return;
 	}
 	double pval;
@@ -401,7 +436,7 @@ template <int K>
 __global__ void __launch_bounds__(SPA5_BLOCK)
 spa5_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, const SpaRec *__restrict__ recs,
 	int *__restrict__ counters, const int *__restrict__ todo, int *__restrict__ cursor,
-	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8)
+	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8, int force_dense)
 {
 	constexpr int KP = (K + 2) & ~1, NW = SPA5_BLOCK / WAVE;
 	__shared__ double sh[6 * NW];
@@ -530,7 +565,7 @@ spa5_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, const S
 			const double nb = (xsum_c - a6[1]) * inv;
 			const double L = a6[2] + fmax(-nb, 0.0), U = a6[3] + fmin(-nb, 0.0);
 			const double mar = 1e-9 * (fabs(L) + fabs(U) + fabs(qtilde) + fabs(qinv));
-			if (!(qtilde < L - mar && qtilde > U + mar && qinv < L - mar && qinv > U + mar)) {
+			if (force_dense || !(qtilde < L - mar && qtilde > U + mar && qinv < L - mar && qinv > U + mar)) {
 				if (tid == 0) fb_dense[atomicAdd(&counters[2], 1)] = v;
 				continue;
 			}

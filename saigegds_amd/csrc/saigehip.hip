@@ -92,7 +92,7 @@ struct sgx_handle {
 	bool fill_attr_set = false;       // spa3_fill's dynamic LDS size has been raised above 64 KiB
 	bool fill_ds_attr_set = false;    // same for spa3_fill_ds
 	// series SPA stage (kern_spa4.h)
-	double *seg4 = nullptr;           // [nseg][SPA4_NS][vcap4] partial sums of one round of flagged variants
+	double *seg4 = nullptr;           // [nseg][NC + 5][vcap4] partial sums of one round of flagged variants
 	int vcap4 = 0, nround4 = 0;
 	bool mom_attr_set = false;        // spa4_moments' dynamic LDS size has been raised above 64 KiB
 	uint8_t *scr5 = nullptr; int *cur5 = nullptr; int nwg5 = 0;   // spa5_kernel: per-workgroup lists, queue cursor
@@ -428,6 +428,11 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		}
 		md.spa_xmax = std::isfinite(l2min) ? 0.25 * std::sqrt(l2min + M_PI * M_PI) : 0.0;
 	}
+	for (int k = 0; k < K; k++) {
+		double mx = 0;
+		for (int i = 0; i < N; i++) mx = std::max(mx, std::fabs(m->t_X[(size_t)i * K + k]));
+		md.Xabs[k] = mx;
+	}
 	for (int a = 0; a < K * K; a++) md.XVX[a] = m->XVX[a];
 	for (int a = 0; a < K; a++) { md.S_a[a] = m->S_a[a]; md.Xmu[a] = (double)xmu[a]; md.Xsum[a] = (double)xsum[a]; }
 #define TRY(x) do { rc = (x); if (rc) { sgx_free(h); return rc; } } while (0)
@@ -489,7 +494,7 @@ static int ensure_recs(sgx_handle *h, size_t n)
 	if (h->recs) HIPCHK(hipFree(h->recs));
 	if (h->fallback) HIPCHK(hipFree(h->fallback));
 	h->recs = nullptr; h->fallback = nullptr; h->recs_cap = 0;
-	HIPCHK(hipMalloc((void **)&h->recs, n * sizeof(SpaRec)));
+	HIPCHK(hipMalloc((void **)&h->recs, 3 * n * sizeof(SpaRec)));   // tier ranges A and B (+ handed-on copies), exact range (dev_common.h)
 	HIPCHK(hipMalloc((void **)&h->fallback, n * sizeof(int)));
 	if (!h->md.quant) {
 		if (h->fb_spa2) HIPCHK(hipFree(h->fb_spa2));
@@ -502,9 +507,9 @@ static int ensure_recs(sgx_handle *h, size_t n)
 		h->nseg = (h->md.N + spa3_seg(h->md.K) - 1) / spa3_seg(h->md.K);
 		if (h->seg4) HIPCHK(hipFree(h->seg4));
 		h->seg4 = nullptr;
-		h->vcap4 = (int)std::min<size_t>(n, 16384);       // flagged variants per round of the series SPA stage
+		h->vcap4 = (int)std::min<size_t>(n, 32768);       // flagged variants per round of the series SPA stage
 		h->nround4 = (int)((n + h->vcap4 - 1) / h->vcap4);
-		HIPCHK(hipMalloc((void **)&h->seg4, (size_t)h->nseg * SPA4_NS * h->vcap4 * sizeof(double)));
+		HIPCHK(hipMalloc((void **)&h->seg4, (size_t)h->nseg * SPA4_NSMAX * h->vcap4 * sizeof(double)));
 		HIPCHK(hipMalloc((void **)&h->segcnt, n * (size_t)h->nseg * sizeof(int)));
 		HIPCHK(hipMalloc((void **)&h->segpart, n * (size_t)h->nseg * SPA3_NSEGP * sizeof(double)));
 		h->fb_spa2 = nullptr; h->heads = nullptr; h->chunks = nullptr; h->partial = nullptr;
@@ -582,7 +587,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		switch (md.K) {
 #define ECASE(KK) case KK:                                                                     \
 	hipLaunchKernelGGL((score_mfma_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), \
-		0, st, (int)M, md, ep, h->mf_acc, h->recs, h->counters, out8, valid); break;
+		0, st, (int)M, md, ep, h->mf_acc, h->recs, h->counters, md.quant ? 0 : (int)(2 * M), h->fb_spa2, out8, valid); break;
 		FOR_EACH_K(ECASE)
 #undef ECASE
 		default: return fail(SGX_EINVAL, "MFMA score path: unsupported K=%d", md.K);
@@ -644,24 +649,37 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			/* series SPA stage (kern_spa4.h): rounds of at most vcap4 flagged variants */   \
 			const size_t fl = spa4_lds_bytes(KK);                                            \
 			if (!h->mom_attr_set) {                                                          \
-				HIPCHK(hipFuncSetAttribute((const void *)spa4_moments<KK>,                   \
+				HIPCHK(hipFuncSetAttribute((const void *)spa4_moments<KK, SPA4_NCA>,         \
+					hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));                   \
+				HIPCHK(hipFuncSetAttribute((const void *)spa4_moments<KK, SPA4_NCB>,         \
 					hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));                   \
 				h->mom_attr_set = true;                                                      \
 			}                                                                                \
 			const int nround = (int)((M + h->vcap4 - 1) / h->vcap4);                         \
+			const int btop = (int)(2 * M);                                                   \
+			const dim3 gsolve((unsigned)((h->vcap4 + 3) / 4));       /* one wave per variant */ \
+			/* tier A (short series), then tier B with what tier A handed on */              \
 			for (int rd = 0; rd < nround; rd++) {                                            \
-				hipLaunchKernelGGL((spa4_moments<KK>), dim3((unsigned)h->n_cu),                  \
+				hipLaunchKernelGGL((spa4_moments<KK, SPA4_NCA>), dim3((unsigned)h->n_cu),    \
 					dim3(WAVE * SPA4_WAVES), fl, st, (const uint8_t *)rows, row_bytes, md,   \
-					h->nseg, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl); \
-				hipLaunchKernelGGL((spa4_solve<KK>), dim3((unsigned)((h->vcap4 + 255) / 256)), dim3(256), 0, st, \
-					md, h->nseg, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4,     \
+					h->nseg, 0, btop, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl); \
+				hipLaunchKernelGGL((spa4_solve<KK, SPA4_NCA>), gsolve, dim3(256), 0, st,     \
+					md, h->nseg, 0, btop, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, \
+					h->fallback, h->fb_spa2, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0); \
+			}                                                                                \
+			for (int rd = 0; rd < nround; rd++) {                                            \
+				hipLaunchKernelGGL((spa4_moments<KK, SPA4_NCB>), dim3((unsigned)h->n_cu),    \
+					dim3(WAVE * SPA4_WAVES), fl, st, (const uint8_t *)rows, row_bytes, md,   \
+					h->nseg, 1, btop, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl); \
+				hipLaunchKernelGGL((spa4_solve<KK, SPA4_NCB>), gsolve, dim3(256), 0, st,     \
+					md, h->nseg, 1, btop, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, \
 					h->fallback, h->fb_spa2, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0); \
 			}                                                                                \
 			/* rare variants (large g t): exact exp/log sums, one workgroup per variant; then the  \
 			   exact dense g_pos / g_neg pass */                                             \
 			hipLaunchKernelGGL((spa5_kernel<KK>), dim3((unsigned)h->nwg5), dim3(SPA5_BLOCK), \
 				0, st, (const uint8_t *)rows, row_bytes, md, h->recs, h->counters,           \
-				h->fb_spa2, h->cur5, h->fallback, h->scr5, out8);                            \
+				h->fb_spa2, h->cur5, h->fallback, h->scr5, out8, h->force_dense ? 1 : 0);    \
 			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
 				row_bytes, md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
 				h->scratch_stride, out8);                                                    \
@@ -718,7 +736,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 #undef CASE
 		}
 		HIPCHK(hipGetLastError());
-		h->stats.spa_launches = (INPUT == IN_2BIT) ? (uint32_t)(2 * ((M + h->vcap4 - 1) / h->vcap4) + 3)
+		h->stats.spa_launches = (INPUT == IN_2BIT) ? (uint32_t)(4 * ((M + h->vcap4 - 1) / h->vcap4) + 2)
 			: (!h->force_v1 ? (uint32_t)(8 + 2 * h->spa_levels) : 1u);
 	}
 	HIPCHK(hipEventRecord(h->ev[2], st));
@@ -771,7 +789,7 @@ static int sync_lane(sgx_handle *h)
 	if (rc) return rc;
 	HIPCHK(hipStreamSynchronize(h->stream));
 	if (h->stats_pending) {
-		h->stats.n_spa = (uint64_t)h->h_counters[0];
+		h->stats.n_spa = (uint64_t)(h->h_counters[0] + h->h_counters[7] - h->h_counters[6] + h->h_counters[5]);   // the tiers (handed-on copies once) + straight to exact
 		h->stats.n_valid = (uint64_t)h->h_counters[1];
 		h->stats.n_spa_dense = (uint64_t)h->h_counters[2];
 		h->stats.n_spa_slow = (uint64_t)h->h_counters[3];

@@ -105,7 +105,10 @@ def series_spa(g, mu, q, m1, var1, nc, polys):
     r2, c2 = root(qinv)
     p = abs(prob(r1, q)) + abs(prob(r2, qinv))
     xmax = np.max(np.abs(g)) * max(abs(r1), abs(r2))
-    last = max(abs(kap[nc] * r1 ** nc / fact[nc]), abs(kap[nc] * r2 ** nc / fact[nc])) / abs(K0(r1))
+    # the guard of kern_spa4.h: last two terms of the K2 series relative to its sum, at both roots
+    def tail(t):
+        return (abs(kap[nc] * t ** (nc - 2) / fact[nc - 2]) + abs(kap[nc - 1] * t ** (nc - 3) / fact[nc - 3])) / abs(K2(t))
+    last = max(tail(r1), tail(r2))
     return p, c1 and c2, xmax, last
 
 
@@ -150,15 +153,18 @@ def main():
         if abs(qt - m1) / math.sqrt(var2) < 2.0:
             continue
         p_ref, conv, _ = orc.saddle_prob_fast(qt, m1, var2, sm.mu, adj, idx)
-        p_ser, conv2, xmax, last = series_spa(adj[idx], sm.mu[idx], qt, m1, var2, nc, polys)
+        try:
+            p_ser, conv2, xmax, last = series_spa(adj[idx], sm.mu[idx], qt, m1, var2, nc, polys)
+        except (ValueError, ZeroDivisionError, OverflowError):
+            continue
         maf = min(AF, 1 - AF)
         rows.append((maf, idx.size, xmax, abs(p_ser / p_ref - 1), last, p_ref, conv, conv2))
     rows.sort(key=lambda r: r[2])
-    print("   maf     nnz    x=max|g t|   |p_ser/p_ref-1|   last-term   p_ref")
+    print("   maf     nnz    x=max|g t|   |p_ser/p_ref-1|   K2 tail     p_ref")
     for r in rows[:: max(1, len(rows) // 60)]:
         print(f"{r[0]:8.5f} {r[1]:7d} {r[2]:10.4f} {r[3]:14.3e} {r[4]:12.3e} {r[5]:10.3e} {r[6]} {r[7]}")
     a = np.array([(r[2], r[3], r[1]) for r in rows])
-    for xm in (0.1, 0.2, 0.3, 0.5, 0.75, 1.0, 1.5, 2.0, 3.0):
+    for xm in (0.05, 0.1, 0.15, 0.2, 0.3, 0.4, 0.5, 0.75, 1.0, 1.5, 2.0, 3.0):
         sel = a[:, 0] <= xm
         if sel.any():
             print(f"x <= {xm}: {sel.sum():5d} variants, carriers {a[sel, 2].sum() / a[:, 2].sum():.3f} of all, "
