@@ -92,7 +92,7 @@ typedef struct sgx_stats {
 	uint64_t n_valid;      /* passed the filter                               */
 	uint64_t n_spa;        /* pval_noadj <= spa.pval, handed to the SPA stage */
 	uint64_t n_spa_dense;  /* of those, needed the exact dense g_pos/g_neg pass */
-	uint64_t n_spa_slow;   /* of those, finished by the per-workgroup kernel    */
+	uint64_t n_spa_slow;   /* of those, through the exact exp/log kernel (not the series) */
 	float ms_score;        /* HIP-event time of the score kernel(s), ms       */
 	float ms_spa;          /* HIP-event time of the SPA kernel(s), ms         */
 	float ms_total;        /* first launch .. last launch complete, ms        */
@@ -160,13 +160,12 @@ int sgx_burden_2bit(sgx_handle *h, const uint8_t *packed, size_t bytes_per_varia
 int sgx_geno_stats_2bit(const uint8_t *packed, size_t bytes_per_variant, int32_t n_samp,
 	size_t n_variants, int device, int32_t *n_valid, int32_t *allele_sum);
 
-/* Tuning / test hooks: "spa_levels" (Newton levels run in lock step before
- * stragglers go to the per-workgroup kernel), "arena_limit" (carriers; 0 = all),
- * "score_v1" (gather kernel instead of the MFMA path), "force_dense" (exact
- * g_pos/g_neg pass for every SPA variant), "lanes" (1 or 2: with 2, successive sgx_scan_2bit_dev
- * calls alternate between two streams with their own workspace, so the SPA stage of one block runs
- * under the score stage of the next; call sgx_sync() before reading any output).  Results never
- * depend on them. */
+/* Tuning / test hooks: "spa_exact" (every flagged variant through the exact exp/log SPA kernel instead
+ * of the cumulant series), "force_dense" (exact g_pos/g_neg pass for every SPA variant), "score_v1"
+ * (FP64 gather score kernel instead of the MFMA path), "lanes" (1 or 2: with 2, successive
+ * sgx_scan_2bit_dev calls alternate between two streams with their own workspace, so the SPA stage of
+ * one block runs under the score stage of the next; call sgx_sync() before reading any output).
+ * Results never depend on them beyond rounding (1e-12). */
 int sgx_set_option(sgx_handle *h, const char *name, long long value);
 
 int sgx_sync(sgx_handle *h);

@@ -1,5 +1,5 @@
-// kern_spa2.h -- SPA stage v2 for 2-bit genotypes: carrier-only extraction,
-// both Newton root searches fused into shared passes over the carrier list.
+// kern_spa2.h -- pieces shared by the SPA kernels: the carrier-only restatement of the scalars,
+// getroot_K1_fast as a state machine, the CGF terms, Lugannani-Rice, the output row.
 // Part of libsaigehip.so (single translation unit: saigehip.hip).
 #pragma once
 
@@ -106,53 +106,6 @@ __global__ void fastmath_selftest_kernel(const double *x, double *y, int nt)
 	else if (i < 2 * nt) y[i] = fast_log(x[i]);
 }
 
-// One pass over the list: K1 and K2 sums (SPATest.cpp:64,79-80) at t1 (root 1)
-// and/or t2 (root 2).  a1/a2 are wave-uniform.
-template <int BLOCK>
-__device__ __forceinline__ void cgf_pass2(bool a1, bool a2, double t1, double t2, int nnz,
-	const double *__restrict__ gl, const double *__restrict__ ml, double *sh, double (&o)[4])
-{
-	double v[4] = {0, 0, 0, 0};
-	for (int k = threadIdx.x; k < nnz; k += BLOCK) {
-		const double g = gl[k], m = ml[k], om = 1 - m;
-		const double mg = m * g, c2 = om * mg * g;
-		if (a1) {
-			const double e = exp(-g * t1);
-			const double d = fma(om, e, m);
-			const double r = isfinite(d) ? fast_rcp(d) : 0.0;
-			v[0] = fma(mg, r, v[0]);
-			const double t = c2 * e * r * r;
-			if (isfinite(t)) v[1] += t;
-		}
-		if (a2) {
-			const double e = exp(-g * t2);
-			const double d = fma(om, e, m);
-			const double r = isfinite(d) ? fast_rcp(d) : 0.0;
-			v[2] = fma(mg, r, v[2]);
-			const double t = c2 * e * r * r;
-			if (isfinite(t)) v[3] += t;
-		}
-	}
-	block_sum<4, BLOCK>(v, sh);
-#pragma unroll
-	for (int a = 0; a < 4; a++) o[a] = v[a];
-}
-
-// Korg sums (SPATest.cpp:49) at both roots
-template <int BLOCK>
-__device__ __forceinline__ void korg_pass2(bool a1, bool a2, double t1, double t2, int nnz,
-	const double *__restrict__ gl, const double *__restrict__ ml, double *sh, double (&o)[2])
-{
-	double v[2] = {0, 0};
-	for (int k = threadIdx.x; k < nnz; k += BLOCK) {
-		const double g = gl[k], m = ml[k], om = 1 - m;
-		if (a1) v[0] += log(fma(m, exp(g * t1), om));
-		if (a2) v[1] += log(fma(m, exp(g * t2), om));
-	}
-	block_sum<2, BLOCK>(v, sh);
-	o[0] = v[0]; o[1] = v[1];
-}
-
 // tail of get_saddle_prob_fast, SPATest.cpp:216-229, Korg/K2 sums given
 __device__ __forceinline__ double lugannani_rice(double t, double Ksum, double k2s, double q,
 	double NAmu, double NAsigma)
@@ -170,153 +123,42 @@ __device__ __forceinline__ double lugannani_rice(double t, double Ksum, double k
 	return pval;
 }
 
-#define SPA2_QCAP 16   /* carriers a thread can queue per chunk = samples per dword */
-
-template <int K, int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
-spa2_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md,
-	const SpaRec *__restrict__ recs, int *__restrict__ counters, int counter_slot,
-	const int *__restrict__ rec_index, int *__restrict__ fallback,
-	double *__restrict__ scratch, size_t scratch_stride, double *__restrict__ out8)
+// final row of a variant that went through Saddle_Prob_Fast (saige_main.cpp:390-403)
+__device__ __forceinline__ void spa_write_row(const SpaRec &r, double Tstat, double var1, double pval,
+	bool converged, double *__restrict__ out8)
 {
-	constexpr int NW = BLOCK / WAVE;
-	constexpr int KP = (K + 2) & ~1;           // row of XM: X_i (K), mu_i, pad
-	__shared__ double sh[8 * NW];
-	__shared__ int shi[NW];
-	__shared__ uint32_t qidx[BLOCK * SPA2_QCAP];
-	const int N = md.N, tid = threadIdx.x;
-	const int lane = tid & (WAVE - 1), wid = tid / WAVE;
-	const int nflag = counters[counter_slot];
-	double *gl = scratch + (size_t)blockIdx.x * scratch_stride;
-	double *ml = gl + scratch_stride / 2;
-	const int ndw = (N + 15) >> 4;
-
-	for (int vi = blockIdx.x; vi < nflag; vi += gridDim.x) {
-		const int v = rec_index ? rec_index[vi] : vi;
-		const SpaRec r = recs[v];
-		const uint32_t *row = reinterpret_cast<const uint32_t *>(packed + (size_t)r.j * bpv);
-		const double inv = 1 / sqrt(r.AC2);
-		const uint32_t zx = r.minus ? 0xAAAAAAAAu : 0u;
-		double c[K];
-#pragma unroll
-		for (int a = 0; a < K; a++) c[a] = r.c[a];
-
-		// ---- carriers: (adj, mu) list + carrier sums
-		// a6: sum mu*G, sum b, sum max(adj,0), sum min(adj,0), sum adj*mu, sum adj^2 mu(1-mu)
-		double a6[6] = {0, 0, 0, 0, 0, 0};
-		int nnz = 0;
-		for (int d0 = 0; d0 < ndw; d0 += BLOCK) {
-			const int d = d0 + tid;
-			const uint32_t w = (d < ndw) ? row[d] : 0u;
-			uint32_t nz = nz_fields((w ^ zx) & keep_mask(N - d * 16));
-			const int cnt = __popc(nz);
-			int incl = cnt;                           // wave inclusive scan
-#pragma unroll
-			for (int o = 1; o < WAVE; o <<= 1) {
-				const int up = __shfl_up(incl, o, WAVE);
-				if (lane >= o) incl += up;
-			}
-			if (lane == WAVE - 1) shi[wid] = incl;
-			__syncthreads();
-			int wbase = 0, total = 0;
-#pragma unroll
-			for (int ww = 0; ww < NW; ww++) { if (ww < wid) wbase += shi[ww]; total += shi[ww]; }
-			int off = wbase + incl - cnt;
-			while (nz) {
-				const int b = __ffs(nz) - 1;
-				nz &= nz - 1;
-				qidx[off++] = (uint32_t)(d * 16 + (b >> 1)) | (((w >> b) & 3u) << 30);
-			}
-			__syncthreads();
-			for (int k = tid; k < total; k += BLOCK) {
-				const uint32_t e = qidx[k];
-				const int i = (int)(e & 0x3FFFFFFFu);
-				const double G = sel4(r.lut, e >> 30);
-				const double *x = md.XM + (size_t)i * KP;
-				double xv[KP];
-#pragma unroll
-				for (int a = 0; a < KP; a += 2) {
-					const double2 t2 = *reinterpret_cast<const double2 *>(x + a);
-					xv[a] = t2.x; xv[a + 1] = t2.y;
-				}
-				double b = 0;
-#pragma unroll
-				for (int a = 0; a < K; a++) b = fma(xv[a], c[a], b);
-				const double mui = xv[K];
-				const double adj = (G - b) * inv;
-				gl[nnz + k] = adj; ml[nnz + k] = mui;
-				a6[0] = fma(mui, G, a6[0]);
-				a6[1] += b;
-				if (adj > 0) a6[2] += adj; else a6[3] += adj;
-				a6[4] = fma(adj, mui, a6[4]);
-				a6[5] = fma(adj * adj, mui * (1 - mui), a6[5]);
-			}
-			nnz += total;
-			__syncthreads();
-		}
-		block_sum<6, BLOCK>(a6, sh);     // barriers also publish the list
-
-		// ---- scalars of saige_main.cpp:369-381
-		double xmu_c = 0, xsum_c = 0;
-#pragma unroll
-		for (int a = 0; a < K; a++) { xmu_c = fma(md.Xmu[a], c[a], xmu_c); xsum_c = fma(md.Xsum[a], c[a], xsum_c); }
-		const double m1 = (a6[0] - xmu_c) * inv;
-		const double Tstat = r.S * inv;
-		const double var2 = r.var2 / r.AC2;
-		const double var1 = var2 * md.r;
-		const double qtilde = Tstat / sqrt(var1) * sqrt(var2) + m1;
-		// Saddle_Prob_Fast(qtilde, m1, var2, ...)
-		const double s = qtilde - m1;
-		const double qinv = -s + m1;
-		const double pn_in = d_pchisq1_upper(s * s / var2);
-		double pval;
-		bool converged = true, need_fallback = false;
-		if (fabs(qtilde - m1) / sqrt(var2) < 2.0) {
-			pval = pn_in;
-		} else {
-			const double nb = (xsum_c - a6[1]) * inv;
-			const double L = a6[2] + fmax(-nb, 0.0), U = a6[3] + fmin(-nb, 0.0);
-			const double mar = 1e-9 * (fabs(L) + fabs(U) + fabs(qtilde) + fabs(qinv));
-			if (!(qtilde < L - mar && qtilde > U + mar && qinv < L - mar && qinv > U + mar)) {
-				need_fallback = true;
-				pval = pn_in;
-			} else {
-				const double NAmu = m1 - a6[4], NAsigma = var2 - a6[5];
-				RootState s1, s2;
-				root_begin(s1, qtilde, L, U);
-				root_begin(s2, qinv, L, U);
-				while (s1.active || s2.active) {
-					double o[4];
-					cgf_pass2<BLOCK>(s1.active, s2.active, s1.tnew, s2.tnew, nnz, gl, ml, sh, o);
-					if (s1.active) root_feed(s1, o[0], o[1], NAmu, NAsigma);
-					if (s2.active) root_feed(s2, o[2], o[3], NAmu, NAsigma);
-				}
-				if (s1.converged && s2.converged) {
-					double ko[2];
-					korg_pass2<BLOCK>(true, true, s1.root, s2.root, nnz, gl, ml, sh, ko);
-					const double p1 = lugannani_rice(s1.root, ko[0], s1.K2cur, qtilde, NAmu, NAsigma);
-					const double p2 = lugannani_rice(s2.root, ko[1], s2.K2cur, qinv, NAmu, NAsigma);
-					pval = fabs(p1) + fabs(p2);
-					if (pval != 0 && pn_in / pval > 1000) pval = pn_in;   // SPATest.cpp:368-371
-				} else {
-					pval = pn_in;
-					converged = false;
-				}
-			}
-		}
-		if (need_fallback) {
-			if (tid == 0) fallback[atomicAdd(&counters[2], 1)] = v;
-			continue;
-		}
-		if (pval == 0 && r.p_noadj > 0) { pval = r.p_noadj; converged = false; }
-		if (tid == 0) {
-			double beta = (Tstat / var1) / sqrt(r.AC2);
-			if (r.minus) beta = -beta;
-			double *o = out8 + (size_t)r.j * 8;
-			o[3] = beta;
-			o[4] = fabs(beta / d_qnorm(pval / 2));
-			o[5] = pval;
-			o[7] = converged ? 1.0 : 0.0;
-		}
-	}
+	if (pval == 0 && r.p_noadj > 0) { pval = r.p_noadj; converged = false; }
+	double beta = (Tstat / var1) / sqrt(r.AC2);
+	if (r.minus) beta = -beta;
+	double *o = out8 + (size_t)r.j * 8;
+	o[3] = beta;
+	o[4] = fabs(beta / d_qnorm(pval / 2));
+	o[5] = pval;
+	o[7] = converged ? 1.0 : 0.0;
 }
+
+// K1, K2 (SPATest.cpp:64,79-80) and Korg (:49) terms of one carrier at t
+template <bool WITH_K>
+__device__ __forceinline__ void cgf_terms(double g, double m, double t, double &k1, double &k2, double &k0)
+{
+	const double om = 1 - m, mg = m * g, c2 = om * mg * g;
+	const double e = fast_exp(-g * t);
+	const double d = fma(om, e, m);
+	const double rr = isfinite(d) ? fast_rcp(d) : 0.0;
+	k1 = fma(mg, rr, k1);
+	const double tt = c2 * e * rr * rr;
+	if (isfinite(tt)) k2 += tt;
+	// log(1 - m + m e^{gt}) = g t + log((1-m) e^{-gt} + m): reuses the exponential;
+	// when e^{-gt} overflows the reference's own form is evaluated instead
+	if (WITH_K) k0 += isfinite(d) ? fma(g, t, fast_log(d)) : fast_log(fma(m, fast_exp(g * t), om));
+}
+
+
+// samples per extraction segment for K covariates: rows of (K + 2) & ~1 doubles, a power of two
+// of them in 128 KiB of LDS, at most 4096
+__host__ __device__ constexpr int spa_seg(int K)
+{
+	const int row = ((K + 2) & ~1) * 8;
+	return row <= 32 ? 4096 : row <= 64 ? 2048 : row <= 128 ? 1024 : 512;
+}
+

@@ -119,7 +119,7 @@ __device__ __forceinline__ int wave_reduce_scatter(double (&x)[V], int lane)
 // dynamic LDS of spa4_moments<K>: the segment's table + the parameter slice
 __host__ __device__ constexpr size_t spa4_lds_bytes(int K)
 {
-	return (size_t)spa3_seg(K) * ((K + 2) & ~1) * 8 + (size_t)SPA4_VPER * (8 + 8 * (K + 6));
+	return (size_t)spa_seg(K) * ((K + 2) & ~1) * 8 + (size_t)SPA4_VPER * (8 + 8 * (K + 6));
 }
 
 // The flagged variants of a call sit in recs[] in two ranges: tier A from slot 0 upwards (counters[0]
@@ -134,7 +134,7 @@ __global__ void __launch_bounds__(WAVE * SPA4_WAVES)
 spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg, int tier, int btop, int v0, int vcap,
 	const SpaRec *__restrict__ recs, const int *__restrict__ counters, double *__restrict__ segpart, int abl)
 {
-	constexpr int SEG = spa3_seg(K), KP = (K + 2) & ~1, NS = NC + 5;
+	constexpr int SEG = spa_seg(K), KP = (K + 2) & ~1, NS = NC + 5;
 	constexpr int LDW = SEG / 16 / WAVE > 0 ? SEG / 16 / WAVE : 1;     // dwords (of 16 samples) per lane
 	constexpr int NLANE = SEG / 16 / LDW;                              // lanes that own samples
 	static_assert(LDW == 1 || LDW == 2 || LDW == 4, "segment sizes 512..4096");
@@ -258,6 +258,103 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 				if (!__ballot(cb.ok)) break;
 				fetch(ca);
 				if (cb.ok) work(cb);
+			}
+			const int idx = wave_reduce_scatter(acc, lane);
+#pragma unroll
+			for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o, WAVE));
+			const size_t base = (size_t)seg * NS * vcap + (vb + vl);
+			if (!(lane & (NS - 1 > 16 ? 1 : 3)) && idx < NS - 1) segpart[base + (size_t)idx * vcap] = acc[0];
+			if (lane == 1) segpart[base + (size_t)(NS - 1) * vcap] = gmax;
+		}
+	}
+}
+
+// Dosage rows (RAW bytes / doubles, kern_spa.h load_dosage): the same sums, but a row of imputed
+// dosages is dense -- nearly every sample is a "carrier" -- so there is nothing to compact: in step j
+// lane l takes sample 64 j + l of the segment (coalesced row loads), skipping the exact zeros.
+template <int K, int NC, int INPUT>
+__global__ void __launch_bounds__(WAVE * SPA4_WAVES)
+spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, int nseg, int tier, int btop, int v0, int vcap,
+	const SpaRec *__restrict__ recs, const int *__restrict__ counters, double *__restrict__ segpart)
+{
+	constexpr int SEG = spa_seg(K), KP = (K + 2) & ~1, NS = NC + 5;
+	extern __shared__ __attribute__((aligned(16))) uint8_t fill_smem[];
+	double *tab = reinterpret_cast<double *>(fill_smem);                                  // [SEG][KP]
+	double *pd = tab + (size_t)SEG * KP;                                                  // [K + 6][VPER]: inv, ts, c[K], lut[4]
+	int *pj = reinterpret_cast<int *>(pd + (size_t)(K + 6) * SPA4_VPER);                 // [VPER] row, [VPER] flip flag
+	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	const int nflag = min(counters[tier ? 7 : 0] - v0, vcap);
+	if (nflag <= 0) return;
+	const int nslice = (nflag + SPA4_VPER - 1) / SPA4_VPER;
+	const long long nitem = (long long)nseg * nslice;
+	const int it0 = (int)(nitem * blockIdx.x / gridDim.x), it1 = (int)(nitem * (blockIdx.x + 1) / gridDim.x);
+	int seg = -1;
+	for (int it = it0; it < it1; it++) {
+		const int sg = it / nslice, vb = (it - sg * nslice) * SPA4_VPER;
+		const int nv = min(SPA4_VPER, nflag - vb);
+		__syncthreads();                     // the previous item's readers are done
+		if (sg != seg) {
+			seg = sg;
+			const int nrow = min(SEG, N - seg * SEG);
+			const double2 *src = reinterpret_cast<const double2 *>(md.XM + (size_t)seg * SEG * KP);
+			double2 *dst = reinterpret_cast<double2 *>(tab);
+			for (int i = tid; i < nrow * (KP / 2); i += WAVE * SPA4_WAVES) dst[i] = src[i];
+		}
+		for (int i = tid; i < nv; i += WAVE * SPA4_WAVES) {
+			const SpaRec &r = recs[spa4_rec(tier, btop, v0 + vb + i)];
+			pj[i] = r.j;
+			pj[SPA4_VPER + i] = r.minus;
+			pd[i] = 1 / sqrt(r.AC2);
+			pd[SPA4_VPER + i] = r.tscale;
+#pragma unroll
+			for (int a = 0; a < K; a++) pd[(2 + a) * SPA4_VPER + i] = r.c[a];
+#pragma unroll
+			for (int a = 0; a < 4; a++) pd[(2 + K + a) * SPA4_VPER + i] = r.lut[a];
+		}
+		__syncthreads();
+		const int s_lo = seg * SEG, nstep = (min(SEG, N - s_lo) + WAVE - 1) / WAVE;
+		for (int vl = wid; vl < nv; vl += SPA4_WAVES) {
+			const double inv = pd[vl], ts = pd[SPA4_VPER + vl];
+			const double imp = pd[(2 + K + 3) * SPA4_VPER + vl];      // lut[3]: the imputed value, flipped already
+			const bool minus = pj[SPA4_VPER + vl] != 0;
+			const uint8_t *row = reinterpret_cast<const uint8_t *>(rows) + (size_t)pj[vl] * row_bytes;
+			double c[K];
+#pragma unroll
+			for (int a = 0; a < K; a++) c[a] = pd[(2 + a) * SPA4_VPER + vl];
+			double acc[NS - 1], gmax = 0;
+#pragma unroll
+			for (int a = 0; a < NS - 1; a++) acc[a] = 0;
+			auto dosage = [&](int j) -> double {               // load_dosage of kern_spa.h on the staged parameters
+				const int i = s_lo + j * WAVE + lane;
+				if (i >= N) return 0.0;
+				if (INPUT == IN_U8) {
+					const uint8_t v = row[i];
+					return (v == 0xFF) ? imp : (minus ? 2.0 - (double)v : (double)v);
+				} else {
+					const double v = reinterpret_cast<const double *>(row)[i];
+					return !isfinite(v) ? imp : (minus ? 2.0 - v : v);
+				}
+			};
+			double gn = dosage(0);
+			for (int j = 0; j < nstep; j++) {
+				const double G = gn;
+				if (j + 1 < nstep) gn = dosage(j + 1);
+				if (G != 0) {
+					const double *x = tab + (size_t)(j * WAVE + lane) * KP;
+					double bb = 0;
+#pragma unroll
+					for (int a = 0; a < K; a++) bb = fma(x[a], c[a], bb);
+					const double mui = x[K];
+					const double adj = (G - bb) * inv;
+					const double u = mui * (1 - mui);
+					acc[0] = fma(mui, G, acc[0]);
+					acc[1] += bb;
+					if (adj > 0) acc[2] += adj; else acc[3] += adj;
+					acc[4] = fma(adj, mui, acc[4]);
+					acc[5] = fma(adj * adj, u, acc[5]);
+					gmax = fmax(gmax, fabs(adj));
+					spa4_cum_terms<NC>(adj * ts, u, 1 - 2 * mui, &acc[6]);
+				}
 			}
 			const int idx = wave_reduce_scatter(acc, lane);
 #pragma unroll
@@ -416,7 +513,7 @@ spa4_solve(DevModel md, int nseg, int tier, int btop, int v0, int vcap, SpaRec *
 #define SPA5_BLOCK 512
 #define SPA5_BIG 2048            /* lists longer than this are started first (they set the kernel's tail) */
 
-// cgf_terms (kern_spa3.h) with the Korg term switched at run time (workgroup-uniform)
+// K1, K2 (SPATest.cpp:64,79-80) and Korg (:49) terms of one carrier at t; the Korg term switched at run time (workgroup-uniform)
 __device__ __noinline__ void cgf_terms_rt(double g, double m, double t, bool with_k, double &k1, double &k2, double &k0)
 {
 	const double om = 1 - m, mg = m * g, c2 = om * mg * g;
@@ -432,9 +529,9 @@ __device__ __noinline__ void cgf_terms_rt(double g, double m, double t, bool wit
 // bytes of scratch per workgroup: (adj, mu) list + index list, N entries each
 __host__ __device__ inline size_t spa5_wg_bytes(int N) { return (((size_t)N + 63) & ~(size_t)63) * (16 + 4); }
 
-template <int K>
+template <int K, int INPUT>
 __global__ void __launch_bounds__(SPA5_BLOCK)
-spa5_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, const SpaRec *__restrict__ recs,
+spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec *__restrict__ recs,
 	int *__restrict__ counters, const int *__restrict__ todo, int *__restrict__ cursor,
 	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8, int force_dense)
 {
@@ -446,7 +543,8 @@ spa5_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, const S
 	double2 *glist = reinterpret_cast<double2 *>(scratch + (size_t)blockIdx.x * spa5_wg_bytes(N));
 	uint32_t *ilist = reinterpret_cast<uint32_t *>(glist + (((size_t)N + 63) & ~(size_t)63));
 	const int ntodo = counters[3];
-	const int nvec = (int)(min((size_t)((N + 63) >> 6) * 16, bpv) / 16);      // uint4 pieces (64 samples) of a row
+	// pieces of 64 samples: a uint4 of a packed row, or 64 dosages
+	const int nvec = INPUT == IN_2BIT ? (int)(min((size_t)((N + 63) >> 6) * 16, bpv) / 16) : (N + 63) >> 6;
 	const int per = ((nvec + NW - 1) / NW + WAVE - 1) & ~(WAVE - 1);          // pieces per wave, whole wave steps
 	for (;;) {
 		__syncthreads();                         // sh_vi, shi and the lists of the previous variant are free
@@ -459,17 +557,30 @@ spa5_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, const S
 		const int v = todo[big_round ? vi : vi - ntodo];
 		if ((recs[v].nnz > SPA5_BIG) != big_round) continue;
 		const SpaRec &r = recs[v];               // fields are read where they are used
-		const uint4 *row = reinterpret_cast<const uint4 *>(packed + (size_t)r.j * bpv);
+		const uint8_t *rowb = reinterpret_cast<const uint8_t *>(rows) + (size_t)r.j * bpv;
+		const uint4 *row = reinterpret_cast<const uint4 *>(rowb);
 		const uint32_t zx = r.minus ? 0xAAAAAAAAu : 0u;
 		const double lut0 = r.lut[0], lut1 = r.lut[1], lut2 = r.lut[2], lut3 = r.lut[3];
 		// ---- index list: sample | code << 30, ascending.  Wave w owns pieces [w per, (w+1) per).
+		// ww/z: codes and carrier bits of piece p (2-bit rows); dosage rows: z[0], z[1] = a 64-bit mask of
+		// the piece's non-zero dosages, bit s = sample 64 p + s
 		auto masks = [&](int p, uint32_t (&ww)[4], uint32_t (&z)[4]) -> int {
-			uint4 w = make_uint4(0u, 0u, 0u, 0u);
-			if (p < nvec) w = row[p];
-			ww[0] = w.x; ww[1] = w.y; ww[2] = w.z; ww[3] = w.w;
 			int cnt = 0;
+			if (INPUT == IN_2BIT) {
+				uint4 w = make_uint4(0u, 0u, 0u, 0u);
+				if (p < nvec) w = row[p];
+				ww[0] = w.x; ww[1] = w.y; ww[2] = w.z; ww[3] = w.w;
 #pragma unroll
-			for (int k = 0; k < 4; k++) { z[k] = nz_fields((ww[k] ^ zx) & keep_mask(N - p * 64 - 16 * k)); cnt += __popc(z[k]); }
+				for (int k = 0; k < 4; k++) { z[k] = nz_fields((ww[k] ^ zx) & keep_mask(N - p * 64 - 16 * k)); cnt += __popc(z[k]); }
+			} else {
+				z[0] = z[1] = z[2] = z[3] = 0;
+				if (p < nvec) {
+					for (int s2 = 0; s2 < 64; s2++) {
+						const int i = p * 64 + s2;
+						if (i < N && load_dosage<INPUT>(rowb, i, r) != 0) { z[s2 >> 5] |= 1u << (s2 & 31); cnt++; }
+					}
+				}
+			}
 			return cnt;
 		};
 		int cnt_w = 0;
@@ -496,13 +607,25 @@ spa5_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, const S
 			}
 			int o2 = o_w + incl - cnt;
 			o_w += __shfl(incl, WAVE - 1, WAVE);
+			if (INPUT == IN_2BIT) {
 #pragma unroll
-			for (int k = 0; k < 4; k++) {
-				uint32_t zz = z[k];
-				while (zz) {
-					const int b = __ffs(zz) - 1;
-					zz &= zz - 1;
-					ilist[o2++] = (uint32_t)(p * 64 + 16 * k + (b >> 1)) | (((ww[k] >> b) & 3u) << 30);
+				for (int k = 0; k < 4; k++) {
+					uint32_t zz = z[k];
+					while (zz) {
+						const int b = __ffs(zz) - 1;
+						zz &= zz - 1;
+						ilist[o2++] = (uint32_t)(p * 64 + 16 * k + (b >> 1)) | (((ww[k] >> b) & 3u) << 30);
+					}
+				}
+			} else {
+#pragma unroll
+				for (int k = 0; k < 2; k++) {
+					uint32_t zz = z[k];
+					while (zz) {
+						const int b = __ffs(zz) - 1;
+						zz &= zz - 1;
+						ilist[o2++] = (uint32_t)(p * 64 + 32 * k + b);
+					}
 				}
 			}
 		}
@@ -532,7 +655,8 @@ spa5_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, const S
 				const int k = k0 + j * SPA5_BLOCK;
 				if (k >= nnz) continue;
 				const uint32_t code = e[j] >> 30;
-				const double G = (code & 2u) ? ((code & 1u) ? lut3 : lut2) : ((code & 1u) ? lut1 : lut0);
+				const double G = INPUT == IN_2BIT ? ((code & 2u) ? ((code & 1u) ? lut3 : lut2) : ((code & 1u) ? lut1 : lut0))
+					: load_dosage<INPUT>(rowb, (int)(e[j] & 0x3FFFFFFFu), r);
 				double b = 0;
 #pragma unroll
 				for (int a = 0; a < K; a++) b = fma(xv[j][a], c[a], b);
@@ -573,7 +697,7 @@ spa5_kernel(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, const S
 			RootState s1, s2;
 			root_begin(s1, qtilde, L, U);
 			root_begin(s2, qinv, L, U);
-			root_feed(s1, a6[4], a6[5], NAmu, NAsigma, 0.0, true);      // t = 0 needs no sweep (kern_spa3.h)
+			root_feed(s1, a6[4], a6[5], NAmu, NAsigma, 0.0, true);      // t = 0 needs no sweep: exp(0) = 1
 			root_feed(s2, a6[4], a6[5], NAmu, NAsigma, 0.0, true);
 			// one sweep: K1, K2 (and Korg where wanted) of the active roots
 			auto sweep = [&](bool a1, bool a2, bool k1w, bool k2w, double t1, double t2, double (&sv)[6]) {

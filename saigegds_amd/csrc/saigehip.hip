@@ -62,7 +62,6 @@ static int fail(int code, const char *fmt, ...)
 #include "kern_score_mfma.h"
 #include "kern_spa.h"
 #include "kern_spa2.h"
-#include "kern_spa3.h"
 #include "kern_spa4.h"
 #include "kern_synth.h"
 #include "kern_grm.h"
@@ -80,21 +79,12 @@ struct sgx_handle {
 	SpaRec *recs = nullptr; size_t recs_cap = 0;
 	int *fallback = nullptr;          // rec indices that need the exact dense pass
 	int *fb_spa2 = nullptr;           // rec indices left to the per-workgroup SPA kernel
-	// level-synchronous SPA (kern_spa3.h)
-	SpaHead *heads = nullptr;
-	double2 *arena = nullptr; unsigned long long arena_cap = 0;
-	unsigned long long *cursor = nullptr;
-	ChunkDesc *chunks = nullptr; double *partial = nullptr; int chunk_cap = 0;
-	int *segcnt = nullptr; double *segpart = nullptr; int nseg = 0;
-	int spa_levels = 12;
-	unsigned long long arena_limit = 0;   // test hook: pretend the arena is this small (0 = real size)
+	int nseg = 0;                     // sample segments of the SPA stage
 	bool force_dense = false;         // test hook: every SPA variant takes the exact dense pass
-	bool fill_attr_set = false;       // spa3_fill's dynamic LDS size has been raised above 64 KiB
-	bool fill_ds_attr_set = false;    // same for spa3_fill_ds
 	// series SPA stage (kern_spa4.h)
 	double *seg4 = nullptr;           // [nseg][NC + 5][vcap4] partial sums of one round of flagged variants
 	int vcap4 = 0, nround4 = 0;
-	bool mom_attr_set = false;        // spa4_moments' dynamic LDS size has been raised above 64 KiB
+	bool mom_attr_set[3] = {false, false, false};   // per input type: the moments kernels' dynamic LDS size has been raised
 	uint8_t *scr5 = nullptr; int *cur5 = nullptr; int nwg5 = 0;   // spa5_kernel: per-workgroup lists, queue cursor
 	int spa_abl = 0;                  // timing experiments (wrong results)
 	bool force_exact = false;         // test hook: every SPA variant takes the exact exp/log kernels
@@ -250,7 +240,6 @@ static int alloc_workspace(sgx_handle *h)
 	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
 	HIPCHK(hipMalloc((void **)&h->counters, 8 * sizeof(int)));
 	HIPCHK(hipHostMalloc((void **)&h->h_counters, 8 * sizeof(int), hipHostMallocDefault));
-	HIPCHK(hipMalloc((void **)&h->cursor, sizeof(unsigned long long)));
 	for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&h->ev[i]));
 	// SPA scratch: one (adj, mu) list of N entries per resident workgroup
 	hipDeviceProp_t prop;
@@ -263,9 +252,6 @@ static int alloc_workspace(sgx_handle *h)
 		h->nwg5 = h->n_cu * 2;
 		HIPCHK(hipMalloc((void **)&h->scr5, (size_t)h->nwg5 * spa5_wg_bytes(N)));
 		HIPCHK(hipMalloc((void **)&h->cur5, sizeof(int)));
-		// arena of (adj, mu) carrier lists shared by all flagged variants of a call
-		h->arena_cap = std::min<unsigned long long>(400000000ull, std::max<unsigned long long>(4000000ull, (unsigned long long)N * 1024ull));
-		HIPCHK(hipMalloc((void **)&h->arena, h->arena_cap * sizeof(double2)));
 	}
 	return SGX_OK;
 }
@@ -476,8 +462,7 @@ extern "C" void sgx_free(sgx_handle *h)
 		(void)hipFree(h->dF); (void)hipFree(h->dX); (void)hipFree(h->dy);
 		(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->dFl);
 	}
-	(void)hipFree(h->fallback); (void)hipFree(h->fb_spa2); (void)hipFree(h->heads);
-	(void)hipFree(h->arena); (void)hipFree(h->cursor); (void)hipFree(h->segcnt); (void)hipFree(h->segpart); (void)hipFree(h->chunks); (void)hipFree(h->partial);
+	(void)hipFree(h->fallback); (void)hipFree(h->fb_spa2);
 	(void)hipFree(h->mf_acc); (void)hipFree(h->seg4); (void)hipFree(h->scr5); (void)hipFree(h->cur5);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
 	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid); (void)hipFree(h->stage_pk); (void)hipFree(h->ds_part);
@@ -498,27 +483,14 @@ static int ensure_recs(sgx_handle *h, size_t n)
 	HIPCHK(hipMalloc((void **)&h->fallback, n * sizeof(int)));
 	if (!h->md.quant) {
 		if (h->fb_spa2) HIPCHK(hipFree(h->fb_spa2));
-		if (h->heads) HIPCHK(hipFree(h->heads));
-		if (h->chunks) HIPCHK(hipFree(h->chunks));
-		if (h->partial) HIPCHK(hipFree(h->partial));
-		if (h->segcnt) HIPCHK(hipFree(h->segcnt));
-		if (h->segpart) HIPCHK(hipFree(h->segpart));
-		h->segcnt = nullptr; h->segpart = nullptr;
-		h->nseg = (h->md.N + spa3_seg(h->md.K) - 1) / spa3_seg(h->md.K);
+		h->fb_spa2 = nullptr;
+		h->nseg = (h->md.N + spa_seg(h->md.K) - 1) / spa_seg(h->md.K);
+		HIPCHK(hipMalloc((void **)&h->fb_spa2, n * sizeof(int)));
 		if (h->seg4) HIPCHK(hipFree(h->seg4));
 		h->seg4 = nullptr;
 		h->vcap4 = (int)std::min<size_t>(n, 32768);       // flagged variants per round of the series SPA stage
 		h->nround4 = (int)((n + h->vcap4 - 1) / h->vcap4);
 		HIPCHK(hipMalloc((void **)&h->seg4, (size_t)h->nseg * SPA4_NSMAX * h->vcap4 * sizeof(double)));
-		HIPCHK(hipMalloc((void **)&h->segcnt, n * (size_t)h->nseg * sizeof(int)));
-		HIPCHK(hipMalloc((void **)&h->segpart, n * (size_t)h->nseg * SPA3_NSEGP * sizeof(double)));
-		h->fb_spa2 = nullptr; h->heads = nullptr; h->chunks = nullptr; h->partial = nullptr;
-		h->chunk_cap = (int)std::min<unsigned long long>(0x7fffffffull, h->arena_cap / SPA3_CHUNK + n);
-		HIPCHK(hipMalloc((void **)&h->fb_spa2, n * sizeof(int)));
-
-		HIPCHK(hipMalloc((void **)&h->heads, n * sizeof(SpaHead)));
-		HIPCHK(hipMalloc((void **)&h->chunks, (size_t)h->chunk_cap * sizeof(ChunkDesc)));
-		HIPCHK(hipMalloc((void **)&h->partial, (size_t)h->chunk_cap * SPA3_NPART * sizeof(double)));
 	}
 	if (h->mf_ok) {
 		if (h->mf_acc) HIPCHK(hipFree(h->mf_acc));
@@ -556,7 +528,6 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	constexpr int SB = 256, PB = 512;
 	hipStream_t st = h->stream;
 	HIPCHK(hipMemsetAsync(h->counters, 0, 8 * sizeof(int), st));
-	HIPCHK(hipMemsetAsync(h->cursor, 0, sizeof(unsigned long long), st));
 	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, sizeof(int), st));
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	const bool use_mf = (INPUT == IN_2BIT) && h->mf_ok && !h->force_v1;
@@ -643,90 +614,49 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	if (!md.quant) {
 		const dim3 sgrid((unsigned)std::min<size_t>(M, (size_t)h->spa_grid));
 		switch (md.K) {
+#define MOMENTS(KK, NCX, TIER, RD)                                                               \
+	do {                                                                                         \
+		if (INPUT == IN_2BIT)                                                                    \
+			hipLaunchKernelGGL((spa4_moments<KK, NCX>), dim3((unsigned)h->n_cu),                 \
+				dim3(WAVE * SPA4_WAVES), fl, st, (const uint8_t *)rows, row_bytes, md, h->nseg,  \
+				TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl); \
+		else                                                                                     \
+			hipLaunchKernelGGL((spa4_moments_ds<KK, NCX, (INPUT == IN_2BIT ? IN_U8 : INPUT)>),   \
+				dim3((unsigned)h->n_cu), dim3(WAVE * SPA4_WAVES), fl, st, rows, row_bytes, md,   \
+				h->nseg, TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4);  \
+		hipLaunchKernelGGL((spa4_solve<KK, NCX>), gsolve, dim3(256), 0, st, md, h->nseg, TIER,   \
+			btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->fallback,         \
+			h->fb_spa2, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0);                   \
+	} while (0)
 #define CASE(KK)                                                                             \
 	case KK:                                                                                 \
-		if (INPUT == IN_2BIT) {                                                              \
-			/* series SPA stage (kern_spa4.h): rounds of at most vcap4 flagged variants */   \
-			const size_t fl = spa4_lds_bytes(KK);                                            \
-			if (!h->mom_attr_set) {                                                          \
-				HIPCHK(hipFuncSetAttribute((const void *)spa4_moments<KK, SPA4_NCA>,         \
-					hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));                   \
-				HIPCHK(hipFuncSetAttribute((const void *)spa4_moments<KK, SPA4_NCB>,         \
-					hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));                   \
-				h->mom_attr_set = true;                                                      \
-			}                                                                                \
-			const int nround = (int)((M + h->vcap4 - 1) / h->vcap4);                         \
-			const int btop = (int)(2 * M);                                                   \
-			const dim3 gsolve((unsigned)((h->vcap4 + 3) / 4));       /* one wave per variant */ \
-			/* tier A (short series), then tier B with what tier A handed on */              \
-			for (int rd = 0; rd < nround; rd++) {                                            \
-				hipLaunchKernelGGL((spa4_moments<KK, SPA4_NCA>), dim3((unsigned)h->n_cu),    \
-					dim3(WAVE * SPA4_WAVES), fl, st, (const uint8_t *)rows, row_bytes, md,   \
-					h->nseg, 0, btop, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl); \
-				hipLaunchKernelGGL((spa4_solve<KK, SPA4_NCA>), gsolve, dim3(256), 0, st,     \
-					md, h->nseg, 0, btop, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, \
-					h->fallback, h->fb_spa2, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0); \
-			}                                                                                \
-			for (int rd = 0; rd < nround; rd++) {                                            \
-				hipLaunchKernelGGL((spa4_moments<KK, SPA4_NCB>), dim3((unsigned)h->n_cu),    \
-					dim3(WAVE * SPA4_WAVES), fl, st, (const uint8_t *)rows, row_bytes, md,   \
-					h->nseg, 1, btop, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl); \
-				hipLaunchKernelGGL((spa4_solve<KK, SPA4_NCB>), gsolve, dim3(256), 0, st,     \
-					md, h->nseg, 1, btop, rd * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, \
-					h->fallback, h->fb_spa2, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0); \
-			}                                                                                \
-			/* rare variants (large g t): exact exp/log sums, one workgroup per variant; then the  \
-			   exact dense g_pos / g_neg pass */                                             \
-			hipLaunchKernelGGL((spa5_kernel<KK>), dim3((unsigned)h->nwg5), dim3(SPA5_BLOCK), \
-				0, st, (const uint8_t *)rows, row_bytes, md, h->recs, h->counters,           \
-				h->fb_spa2, h->cur5, h->fallback, h->scr5, out8, h->force_dense ? 1 : 0);    \
-			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
-				row_bytes, md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
-				h->scratch_stride, out8);                                                    \
-		} else if (h->force_v1) {                                                            \
+		if (h->force_v1 && INPUT != IN_2BIT) {                                               \
 			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
 				row_bytes, md, h->recs, h->counters, 0, (const int *)nullptr, h->scratch,    \
 				h->scratch_stride, out8);                                                    \
 		} else {                                                                             \
-			/* dosage rows: the same level-synchronous stage over (mostly dense) lists */    \
-			const dim3 g256((unsigned)((M + 255) / 256));                                    \
-			const dim3 gchunk((unsigned)(h->n_cu * 8));                                      \
-			const dim3 gitem((unsigned)(h->n_cu * 16));                                      \
-			hipLaunchKernelGGL((spa3_count_ds<INPUT>), gitem, dim3(256), 0, st, rows,        \
-				row_bytes, md.N, h->nseg, spa3_seg(KK), h->recs, h->counters, h->segcnt);    \
-			hipLaunchKernelGGL((spa3_plan<KK>), g256, dim3(256), 0, st, md, h->nseg, h->recs,\
-				h->counters, h->cursor,                                                      \
-				(h->arena_limit ? std::min(h->arena_limit, h->arena_cap) : h->arena_cap),    \
-				h->segcnt, h->heads, h->fb_spa2, out8);                                      \
-			{                                                                                \
-				const size_t fl = (size_t)spa3_seg(KK) * (((KK) + 2) & ~1) * 8;              \
-				const int nslice = std::max(1, (2 * h->n_cu + h->nseg - 1) / h->nseg);       \
-				if (!h->fill_ds_attr_set) {                                                  \
-					HIPCHK(hipFuncSetAttribute((const void *)spa3_fill_ds<KK, INPUT>,        \
-						hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl));               \
-					h->fill_ds_attr_set = true;                                              \
-				}                                                                            \
-				hipLaunchKernelGGL((spa3_fill_ds<KK, INPUT>), dim3((unsigned)std::min(h->nseg * nslice, 4 * h->n_cu)), \
-					dim3(WAVE * SPA3_FILL_WAVES), fl, st, rows, row_bytes, md, h->nseg,      \
-					nslice, h->recs, h->counters, h->segcnt, h->heads, h->arena, h->segpart);\
+			/* series SPA stage (kern_spa4.h): rounds of at most vcap4 flagged variants;     \
+			   tier A (short series), then tier B with what tier A handed on */              \
+			const size_t fl = spa4_lds_bytes(KK);                                            \
+			if (!h->mom_attr_set[INPUT]) {                                                   \
+				const void *fa = INPUT == IN_2BIT ? (const void *)spa4_moments<KK, SPA4_NCA> \
+					: (const void *)spa4_moments_ds<KK, SPA4_NCA, (INPUT == IN_2BIT ? IN_U8 : INPUT)>; \
+				const void *fb = INPUT == IN_2BIT ? (const void *)spa4_moments<KK, SPA4_NCB> \
+					: (const void *)spa4_moments_ds<KK, SPA4_NCB, (INPUT == IN_2BIT ? IN_U8 : INPUT)>; \
+				HIPCHK(hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl)); \
+				HIPCHK(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl)); \
+				h->mom_attr_set[INPUT] = true;                                               \
 			}                                                                                \
-			hipLaunchKernelGGL((spa3_head<KK>), g256, dim3(256), 0, st, md, h->nseg,         \
-				h->recs, h->counters, h->segpart, h->heads, h->chunks, h->chunk_cap,         \
-				h->fallback, h->fb_spa2, out8, h->force_dense ? 1 : 0);                      \
-			for (int lv = 0; lv < h->spa_levels; lv++) {                                     \
-				hipLaunchKernelGGL(spa3_pass, gchunk, dim3(SPA3_BLOCK), 0, st, h->counters,  \
-					h->chunks, h->heads, h->arena, h->partial);                              \
-				hipLaunchKernelGGL(spa3_advance, g256, dim3(256), 0, st, h->counters,        \
-					h->heads, h->partial);                                                   \
-			}                                                                                \
-			hipLaunchKernelGGL(spa3_korg, gchunk, dim3(SPA3_BLOCK), 0, st, h->counters,      \
-				h->chunks, h->heads, h->arena, h->partial);                                  \
-			hipLaunchKernelGGL(spa3_finish, g256, dim3(256), 0, st, h->counters, h->heads,   \
-				h->partial, h->recs, h->fb_spa2, out8);                                      \
-			/* stragglers / arena overflow, then the exact dense g_pos, g_neg pass */        \
-			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
-				row_bytes, md, h->recs, h->counters, 3, h->fb_spa2, h->scratch,              \
-				h->scratch_stride, out8);                                                    \
+			const int nround = (int)((M + h->vcap4 - 1) / h->vcap4);                         \
+			const int btop = (int)(2 * M);                                                   \
+			const dim3 gsolve((unsigned)((h->vcap4 + 3) / 4));       /* one wave per variant */ \
+			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCA, 0, rd);                \
+			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCB, 1, rd);                \
+			/* what the series does not cover: exact exp/log sums, one workgroup per variant; \
+			   then the exact dense g_pos / g_neg pass */                                    \
+			hipLaunchKernelGGL((spa5_kernel<KK, INPUT>), dim3((unsigned)h->nwg5), dim3(SPA5_BLOCK), \
+				0, st, rows, row_bytes, md, h->recs, h->counters, h->fb_spa2, h->cur5,       \
+				h->fallback, h->scr5, out8, h->force_dense ? 1 : 0);                         \
 			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
 				row_bytes, md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
 				h->scratch_stride, out8);                                                    \
@@ -734,10 +664,10 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		break;
 			FOR_EACH_K(CASE)
 #undef CASE
+#undef MOMENTS
 		}
 		HIPCHK(hipGetLastError());
-		h->stats.spa_launches = (INPUT == IN_2BIT) ? (uint32_t)(4 * ((M + h->vcap4 - 1) / h->vcap4) + 2)
-			: (!h->force_v1 ? (uint32_t)(8 + 2 * h->spa_levels) : 1u);
+		h->stats.spa_launches = (h->force_v1 && INPUT != IN_2BIT) ? 1u : (uint32_t)(4 * ((M + h->vcap4 - 1) / h->vcap4) + 2);
 	}
 	HIPCHK(hipEventRecord(h->ev[2], st));
 	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -751,9 +681,7 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 {
 	if (!h || !name) return fail(SGX_EINVAL, "sgx_set_option: NULL argument");
 	const std::string n(name);
-	if (n == "spa_levels") { if (value < 0 || value > 1000) return fail(SGX_EINVAL, "spa_levels out of range"); h->spa_levels = (int)value; }
-	else if (n == "arena_limit") { if (value < 0) return fail(SGX_EINVAL, "arena_limit < 0"); h->arena_limit = (unsigned long long)value; }
-	else if (n == "score_v1") h->force_v1 = value != 0;
+	if (n == "score_v1") h->force_v1 = value != 0;
 	else if (n == "force_dense") h->force_dense = value != 0;
 	else if (n == "spa_exact") h->force_exact = value != 0;
 	else if (n == "spa_abl") h->spa_abl = (int)value;
@@ -769,7 +697,7 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 			for (int g = 0; g < MF_MAXG; g++) { t->mf[g] = h->mf[g]; t->mf_nbfv[g] = h->mf_nbfv[g]; }
 			t->dF = h->dF; t->dX = h->dX; t->dy = h->dy; t->dmu = h->dmu; t->dmu2 = h->dmu2; t->dXM = h->dXM; t->dFl = h->dFl;
 			t->shares_model = true; t->owner = h;
-			t->spa_levels = h->spa_levels; t->arena_limit = h->arena_limit; t->force_dense = h->force_dense; t->force_v1 = h->force_v1; t->force_exact = h->force_exact;
+			t->force_dense = h->force_dense; t->force_v1 = h->force_v1; t->force_exact = h->force_exact;
 			rc = set_dev(t);
 			if (!rc) rc = alloc_workspace(t);
 			if (rc) { sgx_free(t); return rc; }
