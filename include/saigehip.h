@@ -127,6 +127,11 @@ int sgx_score_layout(sgx_handle *h, int32_t *limbs, int32_t n_limbs, int32_t *n_
 int sgx_scan_2bit(sgx_handle *h, const uint8_t *packed, size_t bytes_per_variant,
 	size_t n_variants, double *out8, uint8_t *valid);
 
+/* Page-locked host memory for block buffers handed to the host-buffer scans: from it the chunks cross
+ * PCIe at the full link rate and asynchronously (pageable memory works too, staged by the runtime). */
+void *sgx_host_alloc(size_t bytes);
+void  sgx_host_free(void *p);
+
 /* Same, all buffers already resident in this GPU's HBM (device pointers).
  * packed must be 16-byte aligned and bytes_per_variant a multiple of 64 with
  * bytes_per_variant >= sgx_row_stride(N) = 128*ceil(N/512) (a multiple of 64 that is not one of
@@ -136,9 +141,17 @@ int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev,
 	size_t bytes_per_variant, size_t n_variants, double *out8_dev,
 	uint8_t *valid_dev);
 
-/* Dosage inputs in HOST memory, one row of N values per variant:
- *   u8 : 0..254, 0xFF = missing (RAWSXP);  f64: NaN/Inf = missing (REALSXP). */
+/* Dosage inputs in HOST memory, one row of N values per variant, the three branches of get_ds
+ * (src/saige_main.cpp:171-183):
+ *   u8 : 0..254, 0xFF = missing (RAWSXP :179-182);  i32: NA_INTEGER (INT_MIN) = missing (INTSXP
+ *   :175-178);  f64: NaN/Inf = missing (REALSXP :173-174).
+ * u8 / i32 blocks that hold hard calls only (0, 1, 2, missing) are packed to 2-bit rows on the device
+ * and take the same kernels as sgx_scan_2bit; anything else takes the dosage kernels.
+ * All host-buffer scans are pipelined: the next chunk of the block crosses PCIe while the current
+ * one is computed ("pipe_mb" option = chunk size). */
 int sgx_scan_u8(sgx_handle *h, const uint8_t *dosage, size_t n_variants,
+	double *out8, uint8_t *valid);
+int sgx_scan_i32(sgx_handle *h, const int32_t *dosage, size_t n_variants,
 	double *out8, uint8_t *valid);
 int sgx_scan_f64(sgx_handle *h, const double *dosage, size_t n_variants,
 	double *out8, uint8_t *valid);
@@ -164,7 +177,8 @@ int sgx_geno_stats_2bit(const uint8_t *packed, size_t bytes_per_variant, int32_t
  * of the cumulant series), "force_dense" (exact g_pos/g_neg pass for every SPA variant), "score_v1"
  * (FP64 gather score kernel instead of the MFMA path), "lanes" (1 or 2: with 2, successive
  * sgx_scan_2bit_dev calls alternate between two streams with their own workspace, so the SPA stage of
- * one block runs under the score stage of the next; call sgx_sync() before reading any output).
+ * one block runs under the score stage of the next; call sgx_sync() before reading any output),
+ * "pipe_mb" (MiB of input rows per chunk of a host-buffer scan; 0 = default 512).
  * Results never depend on them beyond rounding (1e-12). */
 int sgx_set_option(sgx_handle *h, const char *name, long long value);
 

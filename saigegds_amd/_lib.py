@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libsaigehip.so")
 
 EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
-    "sgx_set_thresholds", "sgx_score_layout", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_f64", "sgx_burden_2bit", "sgx_geno_stats_2bit",
+    "sgx_set_thresholds", "sgx_score_layout", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_i32", "sgx_scan_f64", "sgx_host_alloc", "sgx_host_free", "sgx_burden_2bit", "sgx_geno_stats_2bit",
     "sgx_sync", "sgx_get_stats", "sgx_get_stats_total", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
     "sgx_grm_init", "sgx_grm_init_dev", "sgx_grm_crossprod_dev", "sgx_grm_sync", "sgx_grm_free", "sgx_grm_diag", "sgx_grm_crossprod", "sgx_grm_pcg",
 )
@@ -105,6 +105,12 @@ def load():
     L.sgx_scan_u8.argtypes = [vp, vp, sz, vp, vp]
     L.sgx_scan_f64.restype = C.c_int
     L.sgx_scan_f64.argtypes = [vp, vp, sz, vp, vp]
+    L.sgx_host_alloc.restype = vp
+    L.sgx_host_alloc.argtypes = [sz]
+    L.sgx_host_free.restype = None
+    L.sgx_host_free.argtypes = [vp]
+    L.sgx_scan_i32.restype = C.c_int
+    L.sgx_scan_i32.argtypes = [vp, vp, sz, vp, vp]
     L.sgx_burden_2bit.restype = C.c_int
     L.sgx_burden_2bit.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp, vp, vp]
     L.sgx_geno_stats_2bit.restype = C.c_int
@@ -211,6 +217,16 @@ class Scanner:
                                   valid.ctypes.data))
         return out, valid
 
+    def scan_i32(self, dosage: np.ndarray):
+        """INTEGER dosages, NA_INTEGER (-2147483648) = missing (the INTSXP branch of get_ds)."""
+        dosage = np.ascontiguousarray(dosage, dtype=np.int32)
+        if dosage.ndim != 2 or dosage.shape[1] != self.n:
+            raise ValueError(f"Invalid length of dosages: {dosage.shape[-1]}.")
+        out, valid = self._out(dosage.shape[0])
+        check(self._L.sgx_scan_i32(self._h, dosage.ctypes.data, dosage.shape[0], out.ctypes.data,
+                                   valid.ctypes.data))
+        return out, valid
+
     def scan_f64(self, dosage: np.ndarray):
         dosage = np.ascontiguousarray(dosage, dtype=np.float64)
         if dosage.ndim != 2 or dosage.shape[1] != self.n:
@@ -275,6 +291,32 @@ class Scanner:
 
     def set_thresholds(self, maf, mac, missing, spa_pval):
         check(self._L.sgx_set_thresholds(self._h, maf, mac, missing, spa_pval))
+
+
+class PinnedBuffer:
+    """Page-locked host memory (``sgx_host_alloc``) as a numpy array: block buffers filled by the GDS
+    decoder and handed to the host-buffer scans cross PCIe at the full link rate."""
+
+    def __init__(self, shape, dtype=np.uint8):
+        self._L = load()
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = self._L.sgx_host_alloc(max(1, self.nbytes))
+        if not self._p:
+            raise MemoryError(self._L.sgx_last_error().decode())
+        buf = (C.c_uint8 * max(1, self.nbytes)).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            self._L.sgx_host_free(self._p)
+            self._p = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 def geno_stats_2bit(packed: np.ndarray, n_samp: int, device: int = 0):

@@ -308,17 +308,18 @@ __device__ __forceinline__ void spa_push(const DevModel &md, SpaRec *recs, int *
 // Score epilogue: from the P reduced sums to the output row; returns 1 when the
 // variant has to go through the SPA stage.
 //   binary saige_main.cpp:313-356, quantitative :225-272
-__device__ int score_epilogue(const DevModel &md, const VarHead &h, const double *acc,
-	double *out, double *c_out, double *p_noadj_out, double *S_out, double *var2_out)
+template <int K>
+__device__ __forceinline__ int score_epilogue(const DevModel &md, const VarHead &h, const double (&acc)[2 * K + 2],
+	double *out, double (&c_out)[KMAX], double *p_noadj_out, double *S_out, double *var2_out)
 {
-	const int K = md.K;
-	const double *c = acc, *e = acc + K;
 	const double s = acc[2 * K], w = acc[2 * K + 1];
 	double quad = 0, ec = 0, sac = 0;
+#pragma unroll
 	for (int a = 0; a < K; a++) {
-		const double ca = c[a];
-		for (int b = 0; b < K; b++) quad += ca * c[b] * md.XVX[a * K + b];
-		ec += e[a] * ca;
+		const double ca = acc[a];
+#pragma unroll
+		for (int b = 0; b < K; b++) quad += ca * acc[b] * md.XVX[a * K + b];
+		ec += acc[K + a] * ca;
 		sac += md.S_a[a] * ca;
 	}
 	const double var2 = quad + w - 2 * ec;
@@ -357,7 +358,8 @@ __device__ int score_epilogue(const DevModel &md, const VarHead &h, const double
 				out[7] = 1.0;
 				return 0;
 			}
-			for (int a = 0; a < K; a++) c_out[a] = c[a];
+#pragma unroll
+			for (int a = 0; a < KMAX; a++) c_out[a] = a < K ? acc[a < K ? a : 0] : 0.0;
 			*p_noadj_out = pval; *S_out = S; *var2_out = var2;
 			return 1;
 		}

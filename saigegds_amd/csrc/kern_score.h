@@ -89,14 +89,16 @@ score2b_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, DevModel m
 		double *o = out8 + (size_t)j * 8;
 		double cbuf[KMAX], pn, Ssc, v2sc;
 		valid[j] = 1;
-		if (score_epilogue(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
+		if (score_epilogue<(P - 2) / 2>(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
 			const int slot = atomicAdd(&counters[0], 1);
 			SpaRec r;
 			r.j = j; r.minus = h.minus; r.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
 			r.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); r.has_gmu = 0; r.sum_gmu = 0;
 			r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc; r.tscale = spa_tscale(Ssc, v2sc, r.AC2, md.r);
 			for (int a = 0; a < 4; a++) r.lut[a] = h.lut[a];
-			for (int a = 0; a < KMAX; a++) r.c[a] = (a < md.K) ? cbuf[a] : 0.0;
+			
+#pragma unroll
+			for (int a = 0; a < KMAX; a++) r.c[a] = cbuf[a];
 			recs[slot] = r;
 		}
 		atomicAdd(&counters[1], 1);
@@ -162,7 +164,7 @@ score_ds_kernel(const T *__restrict__ ds, int M, DevModel md, SpaRec *__restrict
 		double *o = out8 + (size_t)j * 8;
 		double cbuf[KMAX], pn, Ssc, v2sc;
 		valid[j] = 1;
-		if (score_epilogue(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
+		if (score_epilogue<(P - 2) / 2>(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
 			const int slot = atomicAdd(&counters[0], 1);
 			SpaRec r;
 			r.j = j; r.minus = h.minus; r.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
@@ -171,7 +173,9 @@ score_ds_kernel(const T *__restrict__ ds, int M, DevModel md, SpaRec *__restrict
 			// dosage rows carry real values: lut[3] holds the imputed value, the
 			// SPA kernel re-reads the row itself
 			for (int a = 0; a < 4; a++) r.lut[a] = h.lut[a];
-			for (int a = 0; a < KMAX; a++) r.c[a] = (a < md.K) ? cbuf[a] : 0.0;
+			
+#pragma unroll
+			for (int a = 0; a < KMAX; a++) r.c[a] = cbuf[a];
 			recs[slot] = r;
 		}
 		atomicAdd(&counters[1], 1);
@@ -285,7 +289,7 @@ score_ds_tile_epilogue(int M, DevModel md, int nsplit, const double *__restrict_
 	acc[P - 1] = (h.minus ? U[P - 1] : V[P - 1]) + imp * imp * T3[P - 1];
 	double cbuf[KMAX], pn, Ssc, v2sc;
 	valid[j] = 1;
-	if (score_epilogue(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
+	if (score_epilogue<(P - 2) / 2>(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
 		const int slot = atomicAdd(&counters[0], 1);
 		SpaRec r;
 		r.j = j; r.minus = h.minus; r.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
@@ -293,7 +297,9 @@ score_ds_tile_epilogue(int M, DevModel md, int nsplit, const double *__restrict_
 		r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc; r.tscale = spa_tscale(Ssc, v2sc, r.AC2, md.r);
 		// dosage rows carry real values: lut[3] holds the imputed value, the SPA kernel re-reads the row
 		for (int a = 0; a < 4; a++) r.lut[a] = h.lut[a];
-		for (int a = 0; a < KMAX; a++) r.c[a] = (a < md.K) ? cbuf[a] : 0.0;
+		
+#pragma unroll
+			for (int a = 0; a < KMAX; a++) r.c[a] = cbuf[a];
 		recs[slot] = r;
 	}
 	atomicAdd(&counters[1], 1);

@@ -66,6 +66,7 @@ static int fail(int code, const char *fmt, ...)
 #include "kern_synth.h"
 #include "kern_grm.h"
 #include "kern_burden.h"
+#include "kern_pack.h"
 
 // ---------------------------------------------------------------------------
 // host side
@@ -101,6 +102,15 @@ struct sgx_handle {
 	double *scratch = nullptr; size_t scratch_stride = 0; int spa_grid = 0;
 	// host-pointer staging
 	uint8_t *stage_in = nullptr; size_t stage_in_cap = 0;
+	// pipelined host-buffer scans (scan_host): two input buffers, results through pinned memory
+	hipStream_t cstream = nullptr;    // copies of the block that is NOT being computed
+	size_t pipe_bytes = 0;            // test hook: chunk size of the pipeline (0 = PIPE_BYTES)
+	uint8_t *pipe_in[2] = {nullptr, nullptr}; size_t pipe_in_cap = 0;
+	uint8_t *pipe_pk[2] = {nullptr, nullptr}; size_t pipe_pk_cap = 0;       // packed 2-bit rows made on the device
+	double *pipe_out[2] = {nullptr, nullptr}; uint8_t *pipe_valid[2] = {nullptr, nullptr}; size_t pipe_out_cap = 0;
+	double *pin_out[2] = {nullptr, nullptr}; uint8_t *pin_valid[2] = {nullptr, nullptr};   // pinned host
+	int *pipe_flag = nullptr, *h_pipe_flag = nullptr;
+	hipEvent_t ev_h2d = nullptr;
 	uint8_t *stage_pk = nullptr; size_t stage_pk_cap = 0;   // burden: packed rows, CSR and tables
 	double *ds_part = nullptr; size_t ds_part_cap = 0;       // dosage score kernels: per-split partial sums
 	double *stage_out = nullptr; uint8_t *stage_valid = nullptr; size_t stage_out_cap = 0;
@@ -465,6 +475,15 @@ extern "C" void sgx_free(sgx_handle *h)
 	(void)hipFree(h->fallback); (void)hipFree(h->fb_spa2);
 	(void)hipFree(h->mf_acc); (void)hipFree(h->seg4); (void)hipFree(h->scr5); (void)hipFree(h->cur5);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
+	for (int b = 0; b < 2; b++) {
+		(void)hipFree(h->pipe_in[b]); (void)hipFree(h->pipe_pk[b]); (void)hipFree(h->pipe_out[b]); (void)hipFree(h->pipe_valid[b]);
+		if (h->pin_out[b]) (void)hipHostFree(h->pin_out[b]);
+		if (h->pin_valid[b]) (void)hipHostFree(h->pin_valid[b]);
+	}
+	(void)hipFree(h->pipe_flag);
+	if (h->h_pipe_flag) (void)hipHostFree(h->h_pipe_flag);
+	if (h->ev_h2d) (void)hipEventDestroy(h->ev_h2d);
+	if (h->cstream) (void)hipStreamDestroy(h->cstream);
 	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid); (void)hipFree(h->stage_pk); (void)hipFree(h->ds_part);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
 	for (int i = 0; i < 3; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
@@ -542,7 +561,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			const size_t lds = (size_t)2 * 16 * ep.gncol[g] * 16;
 			int *acc = h->mf_acc + ep.goff[g];
 #define MFRUN(NB, B1)                                                                          \
-	do { if (wide && NB <= 3) hipLaunchKernelGGL((score_mfma_kernel<NB, B1, true>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
+	do { if (wide && NB <= 3) hipLaunchKernelGGL((score_mfma_kernel<(NB <= 3 ? NB : 3), B1, true>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
 			(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride);      \
 		else hipLaunchKernelGGL((score_mfma_kernel<NB, B1, false>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
 			(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride); } while (0)
@@ -684,13 +703,14 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 	if (n == "score_v1") h->force_v1 = value != 0;
 	else if (n == "force_dense") h->force_dense = value != 0;
 	else if (n == "spa_exact") h->force_exact = value != 0;
+	else if (n == "pipe_mb") { if (value < 0 || value > 65536) return fail(SGX_EINVAL, "pipe_mb out of range"); h->pipe_bytes = (size_t)value << 20; return SGX_OK; }
 	else if (n == "spa_abl") h->spa_abl = (int)value;
 	else if (n == "lanes") {
 		if (value != 1 && value != 2) return fail(SGX_EINVAL, "lanes must be 1 or 2");
 		if (h->owner) return fail(SGX_EINVAL, "lanes: not on a twin");
 		int rc = sgx_sync(h);
 		if (rc) return rc;
-		if (value == 1 && h->twin) { sgx_free(h->twin); h->twin = nullptr; h->next_lane = 0; }
+		if (value == 1 && h->twin) { sgx_free(h->twin); h->twin = nullptr; h->next_lane = 0; h->last_issued = nullptr; }
 		if (value == 2 && !h->twin) {
 			sgx_handle *t = new sgx_handle();
 			t->device = h->device; t->md = h->md; t->mf_ok = h->mf_ok; t->mfe = h->mfe;
@@ -797,6 +817,8 @@ extern "C" int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev, size_
 	return launch_scan<IN_2BIT>(lane, packed_dev, bpv, M, out8_dev, valid_dev);
 }
 
+static const size_t STAGE_BYTES = (size_t)1 << 30;    // burden rows are made and scanned in chunks of this size
+
 static int ensure_stage(sgx_handle *h, size_t in_bytes, size_t M)
 {
 	if (in_bytes > h->stage_in_cap) {
@@ -816,8 +838,54 @@ static int ensure_stage(sgx_handle *h, size_t in_bytes, size_t M)
 	return SGX_OK;
 }
 
-// host-buffer scans run in chunks so the staging area stays bounded
-static const size_t STAGE_BYTES = (size_t)1 << 30;
+// ---------------------------------------------------------------------------
+// Host-buffer scans: a two-stage pipeline over chunks of the caller's block.  While chunk i is being
+// computed on the handle's stream, chunk i + 1 crosses PCIe on a second stream into the other input
+// buffer; results come back through pinned memory, so no copy of the caller's pageable buffers ever
+// waits for a kernel.  RAW / INTEGER dosages that are hard calls (0, 1, 2, missing) are packed to
+// 2-bit rows on the device (kern_pack.h) and take the MFMA path.
+enum { IN_I32 = 3 };
+static const size_t PIPE_BYTES = (size_t)512 << 20;      // device bytes of one chunk's input rows ("pipe_mb" option)
+
+static int ensure_pipe(sgx_handle *h, size_t in_bytes, size_t pk_bytes, size_t M)
+{
+	if (!h->cstream) {
+		HIPCHK(hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
+		HIPCHK(hipEventCreateWithFlags(&h->ev_h2d, hipEventDisableTiming));
+		HIPCHK(hipMalloc((void **)&h->pipe_flag, sizeof(int)));
+		HIPCHK(hipHostMalloc((void **)&h->h_pipe_flag, sizeof(int), hipHostMallocDefault));
+	}
+	if (in_bytes > h->pipe_in_cap) {
+		for (int b = 0; b < 2; b++) { if (h->pipe_in[b]) HIPCHK(hipFree(h->pipe_in[b])); h->pipe_in[b] = nullptr; }
+		h->pipe_in_cap = 0;
+		for (int b = 0; b < 2; b++) HIPCHK(hipMalloc((void **)&h->pipe_in[b], in_bytes));
+		h->pipe_in_cap = in_bytes;
+	}
+	if (pk_bytes > h->pipe_pk_cap) {
+		for (int b = 0; b < 2; b++) { if (h->pipe_pk[b]) HIPCHK(hipFree(h->pipe_pk[b])); h->pipe_pk[b] = nullptr; }
+		h->pipe_pk_cap = 0;
+		for (int b = 0; b < 2; b++) HIPCHK(hipMalloc((void **)&h->pipe_pk[b], pk_bytes));
+		h->pipe_pk_cap = pk_bytes;
+	}
+	if (M > h->pipe_out_cap) {
+		for (int b = 0; b < 2; b++) {
+			if (h->pipe_out[b]) HIPCHK(hipFree(h->pipe_out[b]));
+			if (h->pipe_valid[b]) HIPCHK(hipFree(h->pipe_valid[b]));
+			if (h->pin_out[b]) HIPCHK(hipHostFree(h->pin_out[b]));
+			if (h->pin_valid[b]) HIPCHK(hipHostFree(h->pin_valid[b]));
+			h->pipe_out[b] = nullptr; h->pipe_valid[b] = nullptr; h->pin_out[b] = nullptr; h->pin_valid[b] = nullptr;
+		}
+		h->pipe_out_cap = 0;
+		for (int b = 0; b < 2; b++) {
+			HIPCHK(hipMalloc((void **)&h->pipe_out[b], M * 8 * sizeof(double)));
+			HIPCHK(hipMalloc((void **)&h->pipe_valid[b], M));
+			HIPCHK(hipHostMalloc((void **)&h->pin_out[b], M * 8 * sizeof(double), hipHostMallocDefault));
+			HIPCHK(hipHostMalloc((void **)&h->pin_valid[b], M, hipHostMallocDefault));
+		}
+		h->pipe_out_cap = M;
+	}
+	return SGX_OK;
+}
 
 template <int INPUT>
 static int scan_host(sgx_handle *h, const void *rows, size_t src_row_bytes, size_t dev_row_bytes,
@@ -828,37 +896,104 @@ static int scan_host(sgx_handle *h, const void *rows, size_t src_row_bytes, size
 	if (!rows || !out8 || !valid) return fail(SGX_EINVAL, "scan: NULL buffer");
 	int rc = set_dev(h);
 	if (rc) return rc;
-	size_t chunk = std::max<size_t>(1, STAGE_BYTES / dev_row_bytes);
-	chunk = std::min(chunk, M);
-	rc = ensure_stage(h, chunk * dev_row_bytes, chunk);
+	rc = sync_lane(h);                        // anything queued on this handle before is done
+	if (rc) return rc;
+	h->last_issued = h;                       // sgx_get_stats: this call, not an earlier one on the twin lane
+	const int N = h->md.N;
+	const size_t pk_row = sgx_row_stride(N);
+	const bool can_pack = (INPUT == IN_U8 || INPUT == IN_I32) && h->mf_ok && !h->force_v1;
+	// a chunk's rows on the device: as they arrive (+ the doubles INTEGER rows may have to become)
+	const size_t per_row = dev_row_bytes + (INPUT == IN_I32 ? (size_t)N * sizeof(double) : 0);
+	size_t chunk = std::min(M, std::max<size_t>(1, (h->pipe_bytes ? h->pipe_bytes : PIPE_BYTES) / per_row));
+	rc = ensure_pipe(h, chunk * per_row, can_pack ? chunk * pk_row : 0, chunk);
 	if (rc) return rc;
 	rc = ensure_recs(h, chunk);
 	if (rc) return rc;
 	sgx_stats total{};
-	for (size_t off = 0; off < M; off += chunk) {
+	auto harvest = [&](size_t off, size_t m, int b) -> int {       // chunk [off, off + m) of buffer b is done
+		int r2 = sync_lane(h);
+		if (r2) return r2;
+		memcpy(out8 + off * 8, h->pin_out[b], m * 8 * sizeof(double));
+		memcpy(valid + off, h->pin_valid[b], m);
+		const sgx_stats &x = h->stats;
+		total.n_variants += x.n_variants; total.n_valid += x.n_valid; total.n_spa += x.n_spa;
+		total.n_spa_dense += x.n_spa_dense; total.n_spa_slow += x.n_spa_slow;
+		total.ms_score += x.ms_score; total.ms_spa += x.ms_spa; total.ms_total += x.ms_total;
+		total.score_launches += x.score_launches; total.spa_launches += x.spa_launches;
+		return SGX_OK;
+	};
+	size_t prev_off = 0, prev_m = 0;
+	int i = 0;
+	for (size_t off = 0; off < M; off += chunk, i++) {
 		const size_t m = std::min(chunk, M - off);
+		const int b = i & 1;
+		// ---- chunk i over PCIe on the copy stream (buffer b was last used by chunk i - 2: done)
 		const uint8_t *src = reinterpret_cast<const uint8_t *>(rows) + off * src_row_bytes;
 		if (src_row_bytes == dev_row_bytes) {
-			HIPCHK(hipMemcpyAsync(h->stage_in, src, m * dev_row_bytes, hipMemcpyHostToDevice, h->stream));
+			HIPCHK(hipMemcpyAsync(h->pipe_in[b], src, m * dev_row_bytes, hipMemcpyHostToDevice, h->cstream));
 		} else {
-			if (dev_row_bytes > src_row_bytes)
-				HIPCHK(hipMemsetAsync(h->stage_in, 0, m * dev_row_bytes, h->stream));
-			HIPCHK(hipMemcpy2DAsync(h->stage_in, dev_row_bytes, src, src_row_bytes,
-				std::min(src_row_bytes, dev_row_bytes), m, hipMemcpyHostToDevice, h->stream));
+			if (dev_row_bytes > src_row_bytes) HIPCHK(hipMemsetAsync(h->pipe_in[b], 0, m * dev_row_bytes, h->cstream));
+			HIPCHK(hipMemcpy2DAsync(h->pipe_in[b], dev_row_bytes, src, src_row_bytes,
+				std::min(src_row_bytes, dev_row_bytes), m, hipMemcpyHostToDevice, h->cstream));
 		}
-		rc = launch_scan<INPUT>(h, h->stage_in, dev_row_bytes, m, h->stage_out, h->stage_valid);
+		bool packed_ok = false;
+		if (can_pack) {
+			HIPCHK(hipMemsetAsync(h->pipe_flag, 0, sizeof(int), h->cstream));
+			const dim3 g((unsigned)std::min<size_t>(64, (pk_row / 4 + 255) / 256), (unsigned)m);
+			if (INPUT == IN_U8)
+				hipLaunchKernelGGL((pack_rows_2bit<uint8_t>), g, dim3(256), 0, h->cstream,
+					(const uint8_t *)h->pipe_in[b], N, h->pipe_pk[b], pk_row, h->pipe_flag);
+			else
+				hipLaunchKernelGGL((pack_rows_2bit<int>), g, dim3(256), 0, h->cstream,
+					(const int *)h->pipe_in[b], N, h->pipe_pk[b], pk_row, h->pipe_flag);
+			HIPCHK(hipGetLastError());
+			HIPCHK(hipMemcpyAsync(h->h_pipe_flag, h->pipe_flag, sizeof(int), hipMemcpyDeviceToHost, h->cstream));
+			HIPCHK(hipStreamSynchronize(h->cstream));
+			packed_ok = *h->h_pipe_flag == 0;
+		}
+		double *as_f64 = nullptr;
+		if (INPUT == IN_I32 && !packed_ok) {
+			as_f64 = reinterpret_cast<double *>(h->pipe_in[b] + chunk * dev_row_bytes);
+			hipLaunchKernelGGL(i32_rows_to_f64, dim3(1024), dim3(256), 0, h->cstream,
+				(const int *)h->pipe_in[b], m * (size_t)N, as_f64);
+			HIPCHK(hipGetLastError());
+		}
+		HIPCHK(hipEventRecord(h->ev_h2d, h->cstream));
+		// ---- chunk i - 1 has been computing meanwhile: collect it
+		if (prev_m) { rc = harvest(prev_off, prev_m, b ^ 1); if (rc) return rc; }
+		// ---- compute chunk i, results to pinned memory
+		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_h2d, 0));
+		if (INPUT == IN_2BIT) rc = launch_scan<IN_2BIT>(h, h->pipe_in[b], dev_row_bytes, m, h->pipe_out[b], h->pipe_valid[b]);
+		else if (packed_ok) rc = launch_scan<IN_2BIT>(h, h->pipe_pk[b], pk_row, m, h->pipe_out[b], h->pipe_valid[b]);
+		else if (INPUT == IN_U8) rc = launch_scan<IN_U8>(h, h->pipe_in[b], dev_row_bytes, m, h->pipe_out[b], h->pipe_valid[b]);
+		else if (INPUT == IN_I32) rc = launch_scan<IN_F64>(h, as_f64, (size_t)N * sizeof(double), m, h->pipe_out[b], h->pipe_valid[b]);
+		else rc = launch_scan<IN_F64>(h, h->pipe_in[b], dev_row_bytes, m, h->pipe_out[b], h->pipe_valid[b]);
 		if (rc) return rc;
-		HIPCHK(hipMemcpyAsync(out8 + off * 8, h->stage_out, m * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-		HIPCHK(hipMemcpyAsync(valid + off, h->stage_valid, m, hipMemcpyDeviceToHost, h->stream));
-		rc = sgx_sync(h);
-		if (rc) return rc;
-		total.n_variants += h->stats.n_variants; total.n_valid += h->stats.n_valid;
-		total.n_spa += h->stats.n_spa; total.n_spa_dense += h->stats.n_spa_dense; total.n_spa_slow += h->stats.n_spa_slow; total.ms_score += h->stats.ms_score;
-		total.ms_spa += h->stats.ms_spa; total.ms_total += h->stats.ms_total;
-		total.score_launches += h->stats.score_launches; total.spa_launches += h->stats.spa_launches;
+		HIPCHK(hipMemcpyAsync(h->pin_out[b], h->pipe_out[b], m * 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+		HIPCHK(hipMemcpyAsync(h->pin_valid[b], h->pipe_valid[b], m, hipMemcpyDeviceToHost, h->stream));
+		prev_off = off; prev_m = m;
 	}
+	rc = harvest(prev_off, prev_m, (i - 1) & 1);
+	if (rc) return rc;
 	h->stats = total;
 	return SGX_OK;
+}
+
+// Page-locked host memory for the caller's block buffers: copies from it run at the full PCIe rate
+// and truly asynchronously (a pageable source is staged by the runtime at ~50 GB/s).
+extern "C" void *sgx_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+		(void)fail(SGX_ENOMEM, "sgx_host_alloc: cannot pin %zu bytes", bytes);
+		return nullptr;
+	}
+	return p;
+}
+
+extern "C" void sgx_host_free(void *p)
+{
+	if (p) (void)hipHostFree(p);
 }
 
 extern "C" int sgx_scan_2bit(sgx_handle *h, const uint8_t *packed, size_t bpv, size_t M,
@@ -874,6 +1009,12 @@ extern "C" int sgx_scan_u8(sgx_handle *h, const uint8_t *dosage, size_t M, doubl
 {
 	const size_t rb = h ? (size_t)h->md.N : 0;
 	return scan_host<IN_U8>(h, dosage, rb, rb, M, out8, valid);
+}
+
+extern "C" int sgx_scan_i32(sgx_handle *h, const int32_t *dosage, size_t M, double *out8, uint8_t *valid)
+{
+	const size_t rb = h ? (size_t)h->md.N * sizeof(int32_t) : 0;
+	return scan_host<IN_I32>(h, dosage, rb, rb, M, out8, valid);
 }
 
 extern "C" int sgx_scan_f64(sgx_handle *h, const double *dosage, size_t M, double *out8, uint8_t *valid)
@@ -904,6 +1045,7 @@ extern "C" int sgx_burden_2bit(sgx_handle *h, const uint8_t *packed, size_t bpv,
 			return fail(SGX_EINVAL, "sgx_burden_2bit: variant index %d out of range", var_idx[e]);
 	int rc = set_dev(h);
 	if (rc) return rc;
+	h->last_issued = h;
 	// device copies: packed rows (4-byte aligned stride), CSR, tables
 	const size_t dbpv = ((size_t)(N + 15) / 16) * 4;
 	const size_t o_ptr = (n_variants * dbpv + 15) & ~(size_t)15;
@@ -928,7 +1070,7 @@ extern "C" int sgx_burden_2bit(sgx_handle *h, const uint8_t *packed, size_t bpv,
 	HIPCHK(hipStreamSynchronize(h->stream));      // rp is a local
 	const size_t row_bytes = (size_t)N * sizeof(double);
 	size_t chunk = std::max<size_t>(1, STAGE_BYTES / row_bytes);
-	chunk = std::min(chunk, n_rows);
+	chunk = std::min<size_t>(std::min(chunk, n_rows), 65535);       // grid.y of burden_collapse_kernel
 	rc = ensure_stage(h, chunk * row_bytes, chunk);
 	if (rc) return rc;
 	rc = ensure_recs(h, chunk);

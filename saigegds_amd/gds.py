@@ -73,12 +73,15 @@ class GdsNode:
 
 
 class GdsFile:
-    """Read-only view of a GDS file (whole file is held in memory)."""
+    """Read-only view of a GDS file.  The file is memory-mapped; array nodes can be read whole
+    (``read``) or by row ranges (``read_rows``, ``dosage_alt_packed_range``), which decode only
+    the LZMA_RA blocks that hold the range -- the scan never has the genotype node in RAM."""
 
     def __init__(self, path: str):
+        import mmap
         self.path = path
-        with open(path, "rb") as f:
-            self.buf = f.read()
+        self._fh = open(path, "rb")
+        self.buf = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
         if self.buf[:len(_MAGIC)] != _MAGIC:
             raise GdsError(f"{path}: not a CoreArray GDS file")
         self.root_id = struct.unpack_from("<I", self.buf, 14)[0]
@@ -119,6 +122,90 @@ class GdsFile:
         if bid not in self._streams:
             raise GdsError(f"no stream with id {bid}")
         return b"".join(self.buf[p:p + n] for p, n in self._streams[bid])
+
+    def stream_size(self, bid: int) -> int:
+        return sum(n for _, n in self._streams[bid])
+
+    def stream_read(self, bid: int, off: int, n: int) -> bytes:
+        """Bytes [off, off + n) of a stream without materialising the rest of it."""
+        out, pos = [], 0
+        for p, ln in self._streams[bid]:
+            lo, hi = max(off, pos), min(off + n, pos + ln)
+            if lo < hi:
+                out.append(self.buf[p + lo - pos:p + hi - pos])
+            pos += ln
+            if pos >= off + n:
+                break
+        return b"".join(out)
+
+    def _ra_index(self, nd: "GdsNode"):
+        """Block table of an LZMA_RA stream: (stream offset, compressed size, raw offset, raw size).
+        Stream layout: "XZ_RA" u8[3] u32 nblk u48 index_offset(after the 18-byte header) xz-blocks
+        index[nblk] of (u24 compressed size, u32 raw size)."""
+        if getattr(nd, "_ra", None) is None:
+            head = self.stream_read(nd.data_id, 0, 18)
+            if head[:5] != b"XZ_RA":
+                raise GdsError("bad LZMA_RA header")
+            nblk = struct.unpack_from("<I", head, 8)[0]
+            ioff = _u48(head, 12) + 18
+            idx = self.stream_read(nd.data_id, ioff, 7 * nblk)
+            tab, so, ro = [], 18, 0
+            for k in range(nblk):
+                cs = int.from_bytes(idx[7 * k:7 * k + 3], "little")
+                rs = struct.unpack_from("<I", idx, 7 * k + 3)[0]
+                tab.append((so, cs, ro, rs))
+                so += cs
+                ro += rs
+            nd._ra, nd._ra_cache = tab, (-1, b"")
+        return nd._ra
+
+    def raw_range(self, path: str, lo: int, hi: int) -> bytes:
+        """Bytes [lo, hi) of the decompressed payload of an array node."""
+        nd = self.node(path)
+        if nd.is_folder or nd.data_id is None:
+            raise GdsError(f"{path}: not an array node")
+        pipe = nd.pipe.upper()
+        if pipe == "":
+            return self.stream_read(nd.data_id, lo, hi - lo)
+        if not pipe.startswith("LZMA_RA"):
+            return self.raw(path)[lo:hi]              # one XZ stream: no random access
+        out = []
+        for k, (so, cs, ro, rs) in enumerate(self._ra_index(nd)):
+            if ro + rs <= lo or ro >= hi:
+                continue
+            if nd._ra_cache[0] != k:
+                blk = lzma.LZMADecompressor(format=lzma.FORMAT_XZ).decompress(self.stream_read(nd.data_id, so, cs))
+                if len(blk) != rs:
+                    raise GdsError("LZMA_RA block size mismatch")
+                nd._ra_cache = (k, blk)
+            blk = nd._ra_cache[1]
+            out.append(blk[max(lo, ro) - ro:min(hi, ro + rs) - ro])
+        return b"".join(out)
+
+    def read_rows(self, path: str, r0: int, r1: int) -> np.ndarray:
+        """Rows [r0, r1) of a fixed-width array node (first dimension), decoding only what is needed."""
+        nd = self.node(path)
+        cls, dims = nd.cls or "", tuple(nd.dims or ())
+        width = {"dInt32": 4, "dUInt32": 4, "dInt8": 1, "dUInt8": 1, "dInt16": 2, "dUInt16": 2, "dFloat32": 4,
+                 "dFloat64": 8, "dPackedReal8U": 1, "dPackedReal8": 1}.get(cls)
+        if width is None or not dims:
+            raise GdsError(f"{path}: read_rows needs a fixed-width array, not {cls!r}")
+        per = int(np.prod(dims[1:])) if len(dims) > 1 else 1
+        data = self.raw_range(path, r0 * per * width, r1 * per * width)
+        shape = (r1 - r0,) + dims[1:]
+        if cls in ("dPackedReal8U", "dPackedReal8"):
+            by = np.frombuffer(data, dtype=np.uint8)
+            if cls == "dPackedReal8U":
+                out = by.astype(np.float64) * nd.scale + nd.offset
+                out[by == 0xFF] = np.nan
+            else:
+                sb = by.view(np.int8)
+                out = sb.astype(np.float64) * nd.scale + nd.offset
+                out[sb == -128] = np.nan
+            return out.reshape(shape)
+        dt = {"dInt32": "<i4", "dUInt32": "<u4", "dInt8": np.int8, "dUInt8": np.uint8, "dInt16": "<i2",
+              "dUInt16": "<u2", "dFloat32": "<f4", "dFloat64": "<f8"}[cls]
+        return np.frombuffer(data, dtype=dt).reshape(shape)
 
     # ------------------------------------------------------------------
     def _load_folder(self, node: GdsNode):
@@ -248,29 +335,80 @@ class GdsFile:
         nd = self.node("genotype/data", silent=True)
         return nd is not None
 
-    def dosage_alt_packed(self) -> Tuple[np.ndarray, int, int]:
-        """``$dosage_alt`` of every variant as 2-bit codes, 4 samples per byte.
-
-        Returns (packed[M, ceil(N/4)] uint8, N, M); code = number of alt
-        alleles (allele index 1), 3 = missing (any allele code 3).  Only
-        biallelic storage (2 bits per allele) with ploidy 2 is supported.
-        """
+    def genotype_dims(self) -> Tuple[int, int]:
+        """(variants, samples) of genotype/data after the checks of ``dosage_alt_packed``."""
         nd = self.node("genotype/data")
         if nd.cls != "dBit2" or len(nd.dims) != 3:
             raise GdsError("genotype/data: expected dBit2 [variant, sample, ploidy]")
         M, N, P = nd.dims
         if P != 2:
             raise GdsError("only diploid genotypes are supported")
-        at = self.node("genotype/@data", silent=True)
-        if at is not None:
-            reps = np.asarray(self.read("genotype/@data")).reshape(-1)
-            if reps.size and not np.all(reps == 1):
-                raise GdsError("multi-allelic (>2 bits) genotype storage is not supported")
-        al = self.read("genotype/data").reshape(M, N, 2)
-        miss = (al == 3).any(axis=2)
-        ds = (al == 1).sum(axis=2).astype(np.uint8)
-        ds[miss] = 3
-        return pack_dosage_2bit(ds), N, M
+        if not getattr(nd, "_reps_ok", False):
+            if self.node("genotype/@data", silent=True) is not None:
+                reps = np.asarray(self.read("genotype/@data")).reshape(-1)
+                if reps.size and not np.all(reps == 1):
+                    raise GdsError("multi-allelic (>2 bits) genotype storage is not supported")
+            nd._reps_ok = True
+        return M, N
+
+    # per byte of genotype/data (two samples x two 2-bit allele codes) -> the two samples' dosage codes in
+    # the low 4 bits.  $dosage_alt counts every non-reference allele (R/assoc_single.r:69-85 reads SeqArray's
+    # $dosage_alt): allele codes 1 and 2 both count, 3 = missing makes the sample missing (code 3).
+    _NIB = None
+
+    @classmethod
+    def _nibble_lut(cls):
+        if cls._NIB is None:
+            lut = np.zeros(256, dtype=np.uint8)
+            for b in range(256):
+                v = 0
+                for smp in range(2):
+                    a0, a1 = (b >> (4 * smp)) & 3, (b >> (4 * smp + 2)) & 3
+                    d = 3 if (a0 == 3 or a1 == 3) else int(a0 != 0) + int(a1 != 0)
+                    v |= d << (2 * smp)
+                lut[b] = v
+            cls._NIB = lut
+        return cls._NIB
+
+    def dosage_alt_packed_range(self, v0: int, v1: int, sample_sel: Optional[np.ndarray] = None) -> np.ndarray:
+        """``$dosage_alt`` of variants [v0, v1) as 2-bit codes, 4 samples per byte: code = number of
+        non-reference alleles, 3 = missing (any allele missing).  ``sample_sel``: sample indices to
+        keep, in the order wanted.  Only the LZMA_RA blocks that hold the range are decoded."""
+        M, N = self.genotype_dims()
+        v0, v1 = max(0, v0), min(M, v1)
+        m = v1 - v0
+        bits0, bits1 = v0 * N * 4, v1 * N * 4
+        data = np.frombuffer(self.raw_range("genotype/data", bits0 // 8, (bits1 + 7) // 8), dtype=np.uint8)
+        if N % 2 == 0 and sample_sel is None:
+            nib = self._nibble_lut()[data.reshape(m, N // 2)]          # rows are whole bytes
+            if (N // 2) % 2:
+                nib = np.concatenate([nib, np.zeros((m, 1), np.uint8)], axis=1)
+            return (nib[:, 0::2] | (nib[:, 1::2] << 4)).astype(np.uint8)
+        v = np.empty((data.size, 4), dtype=np.uint8)
+        for k in range(4):
+            v[:, k] = (data >> (2 * k)) & 3
+        al = v.reshape(-1)[(bits0 % 8) // 2:][:m * N * 2].reshape(m, N, 2)
+        ds = ((al != 0) & (al != 3)).sum(axis=2).astype(np.uint8)
+        ds[(al == 3).any(axis=2)] = 3
+        if sample_sel is not None:
+            ds = ds[:, sample_sel]
+        return pack_dosage_2bit(ds)
+
+    def dosage_alt_packed(self) -> Tuple[np.ndarray, int, int]:
+        """``$dosage_alt`` of every variant (see ``dosage_alt_packed_range``) -> (packed, N, M)."""
+        M, N = self.genotype_dims()
+        return self.dosage_alt_packed_range(0, M), N, M
+
+    def dosage_real_range(self, path: str, v0: int, v1: int) -> np.ndarray:
+        """Rows [v0, v1) of a real-valued dosage node [M, N] (NaN = missing)."""
+        nd = self.node(path + "/data")
+        if not getattr(nd, "_reps_ok", False):
+            if self.node(path + "/@data", silent=True) is not None:
+                reps = np.asarray(self.read(path + "/@data")).reshape(-1)
+                if reps.size and not np.all(reps == 1):
+                    raise GdsError(f"{path}: more than one value per variant")
+            nd._reps_ok = True
+        return np.asarray(self.read_rows(path + "/data", v0, v1), dtype=np.float64)
 
     def dosage_real(self, path: str = "annotation/format/DS") -> np.ndarray:
         """Real-valued dosages [M, N] (NaN = missing) from a format node."""
