@@ -115,17 +115,18 @@ def seqAssocGLMM_SPA(gdsfile: Union[str, GdsFile, GenotypeSource], modobj: Any, 
     sel = np.asarray(sel, dtype=np.int64)
     n_samp = sel.size
 
-    # genotypes of the selected samples
+    # where the genotypes come from; nothing is decoded yet (the reference never holds more than one
+    # block of .bl_size variants either, R/assoc_single.r:202-209)
     if isinstance(src, GenotypeSource):
-        packed, dosage = src.packed, src.dosage
+        kind = "packed" if src.packed is not None else "dosage"
         n_all = len(gsid)
+        n_var = (src.packed if src.packed is not None else src.dosage).shape[0]
     elif node == "$dosage_alt":
-        packed, n_all, _ = src.dosage_alt_packed()
-        dosage = None
+        kind = "packed"
+        n_var, n_all = src.genotype_dims()
     else:
-        dosage = src.dosage_real(node)
-        packed, n_all = None, dosage.shape[1]
-    n_var = (packed if packed is not None else dosage).shape[0]
+        kind = "dosage"
+        n_var, n_all = src.node(node + "/data").dims[:2]
     if verbose:
         print(f"    # of samples: {_pretty(n_samp)}")
         print(f"    # of variants: {_pretty(n_var)}")
@@ -141,11 +142,22 @@ def seqAssocGLMM_SPA(gdsfile: Union[str, GdsFile, GenotypeSource], modobj: Any, 
         raise ValueError("No sample in the genotypic data set!")
     if n_var <= 0:
         raise ValueError("No variant in the genotypic data set!")
-    if not (n_samp == n_all and np.array_equal(sel, np.arange(n_all))):
-        if packed is not None:
-            packed = pack_dosage_2bit(unpack_dosage_2bit(packed, n_all)[:, sel])
-        else:
-            dosage = np.ascontiguousarray(dosage[:, sel])
+    all_samples = n_samp == n_all and np.array_equal(sel, np.arange(n_all))
+
+    def read_block(off: int, end: int):
+        """Genotypes of variants [off, end) for the selected samples."""
+        if isinstance(src, GenotypeSource):
+            if kind == "packed":
+                blk = src.packed[off:end]
+                if not all_samples:
+                    blk = pack_dosage_2bit(unpack_dosage_2bit(blk, n_all)[:, sel])
+                return blk
+            blk = src.dosage[off:end]
+            return blk if all_samples else np.ascontiguousarray(blk[:, sel])
+        if kind == "packed":
+            return src.dosage_alt_packed_range(off, end, None if all_samples else sel)
+        blk = src.dosage_real_range(node, off, end)
+        return blk if all_samples else np.ascontiguousarray(blk[:, sel])
 
     mobj: ScanModel = init_nullmod(mod, ii, maf, mac, missing, spa_pval, var_ratio)
     if mod.trait_type not in ("binary", "quantitative"):
@@ -162,24 +174,12 @@ def seqAssocGLMM_SPA(gdsfile: Union[str, GdsFile, GenotypeSource], modobj: Any, 
     if verbose:
         print(f"    # of GPUs: {ngpu}")
 
-    # scan by blocks, R/assoc_single.r:199-223
+    # scan by blocks of .bl_size variants, R/assoc_single.r:199-223; results land at the blocks' own
+    # offsets, so the table keeps the file's order whatever GPU finishes first (:226-227)
     out = np.empty((n_var, 8), dtype=np.float64)
     valid = np.zeros(n_var, dtype=np.uint8)
-    scanners = [Scanner(mobj, device=d) for d in range(ngpu)]
-    try:
-        for bi, off in enumerate(range(0, n_var, BLOCK_SIZE)):
-            sc = scanners[bi % ngpu]
-            end = min(n_var, off + BLOCK_SIZE)
-            if packed is not None:
-                o, v = sc.scan_2bit(packed[off:end])
-            elif dosage.dtype == np.uint8:
-                o, v = sc.scan_u8(dosage[off:end])
-            else:
-                o, v = sc.scan_f64(dosage[off:end])
-            out[off:end], valid[off:end] = o, v
-    finally:
-        for sc in scanners:
-            sc.close()
+    blocks = [(off, min(n_var, off + BLOCK_SIZE)) for off in range(0, n_var, BLOCK_SIZE)]
+    scan_blocks(lambda d: Scanner(mobj, device=d), ngpu, blocks, read_block, kind == "packed", out, valid)
 
     x = valid.astype(bool)           # R/assoc_single.r:225-234
     if verbose:
@@ -198,6 +198,55 @@ def seqAssocGLMM_SPA(gdsfile: Union[str, GdsFile, GenotypeSource], modobj: Any, 
     if verbose:
         print("Done.")
     return ans
+
+
+def scan_blocks(make_scanner, ngpu: int, blocks, read_block, packed_rows: bool, out: np.ndarray, valid: np.ndarray):
+    """One host thread per GPU (the reference forks one SeqArray worker per core, seqParallel,
+    R/assoc_single.r:202-204): each thread owns a scanner, pulls the next block from a shared queue,
+    decodes it (lzma and numpy release the GIL) and scans it (the C ABI call releases the GIL), so the
+    GPUs work concurrently and a block's decode overlaps the other GPUs' scans."""
+    import queue
+    import threading
+    todo: "queue.Queue" = queue.Queue()
+    for b in blocks:
+        todo.put(b)
+    errors: List[BaseException] = []
+
+    def worker(d: int):
+        sc = None
+        try:
+            sc = make_scanner(d)
+            while not errors:
+                try:
+                    off, end = todo.get_nowait()
+                except queue.Empty:
+                    break
+                blk = read_block(off, end)
+                if packed_rows:
+                    o, v = sc.scan_2bit(blk)            # 2-bit packed rows
+                elif blk.dtype == np.uint8:
+                    o, v = sc.scan_u8(blk)
+                elif np.issubdtype(blk.dtype, np.integer):
+                    o, v = sc.scan_i32(blk)
+                else:
+                    o, v = sc.scan_f64(blk)
+                out[off:end], valid[off:end] = o, v
+        except BaseException as e:      # noqa: BLE001 -- re-raised in the caller's thread
+            errors.append(e)
+        finally:
+            if sc is not None:
+                sc.close()
+
+    if ngpu == 1:
+        worker(0)
+    else:
+        threads = [threading.Thread(target=worker, args=(d,), name=f"sgx-gpu{d}") for d in range(ngpu)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
 
 
 def assemble_result(src, keep: np.ndarray, out: np.ndarray, trait_type: str) -> Dict[str, Any]:

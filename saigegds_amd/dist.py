@@ -60,6 +60,10 @@ def scan_sharded(scanner, packed_local_dev, bpv: int, group=None, n_variants: Op
     # blocks of 50 000 variants (.bl_size, R/assoc_single.r:204) on the library's two lanes: the SPA
     # stage of one block runs under the score stage of the next
     scanner.set_option("lanes", 2)
+    if packed_local_dev.is_cuda:
+        # the library launches on its own non-blocking streams: whatever torch stream produced the
+        # shard (an unpack kernel, a non_blocking copy) has to be finished first
+        torch.cuda.current_stream(packed_local_dev.device).synchronize()
     for lo in range(0, m, block):
         hi = min(m, lo + block)
         scanner.scan_2bit_dev(packed_local_dev[lo:hi].data_ptr(), bpv, hi - lo, out[lo:hi].data_ptr(),

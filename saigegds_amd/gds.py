@@ -81,7 +81,9 @@ class GdsFile:
         import mmap
         self.path = path
         self._fh = open(path, "rb")
+        import threading
         self.buf = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        self._tls = threading.local()
         if self.buf[:len(_MAGIC)] != _MAGIC:
             raise GdsError(f"{path}: not a CoreArray GDS file")
         self.root_id = struct.unpack_from("<I", self.buf, 14)[0]
@@ -156,7 +158,7 @@ class GdsFile:
                 tab.append((so, cs, ro, rs))
                 so += cs
                 ro += rs
-            nd._ra, nd._ra_cache = tab, (-1, b"")
+            nd._ra = tab
         return nd._ra
 
     def raw_range(self, path: str, lo: int, hi: int) -> bytes:
@@ -170,15 +172,16 @@ class GdsFile:
         if not pipe.startswith("LZMA_RA"):
             return self.raw(path)[lo:hi]              # one XZ stream: no random access
         out = []
+        cache = self._tls.__dict__.setdefault("ra", {})     # last decoded block per node, per thread
         for k, (so, cs, ro, rs) in enumerate(self._ra_index(nd)):
             if ro + rs <= lo or ro >= hi:
                 continue
-            if nd._ra_cache[0] != k:
+            if cache.get(path, (-1, b""))[0] != k:
                 blk = lzma.LZMADecompressor(format=lzma.FORMAT_XZ).decompress(self.stream_read(nd.data_id, so, cs))
                 if len(blk) != rs:
                     raise GdsError("LZMA_RA block size mismatch")
-                nd._ra_cache = (k, blk)
-            blk = nd._ra_cache[1]
+                cache[path] = (k, blk)
+            blk = cache[path][1]
             out.append(blk[max(lo, ro) - ro:min(hi, ro + rs) - ro])
         return b"".join(out)
 

@@ -85,10 +85,10 @@ def _compress(raw: bytes, res_compress: str) -> bytes:
 
 
 def save_result(ans: Dict[str, Any], fn: str, res_compress: str = "LZMA", sample_id: List[str] = None):
-    if re.search(r"\.gds$", fn, re.I):
-        raise NotImplementedError(
-            "writing the SAIGE_OUTPUT GDS container is outside this build's scope "
-            "(SURVEY.md 8(f) rank 4); use an .rds or .RData file name")
+    if re.search(r"\.gds$", fn, re.I):            # R/assoc_single.r:243-286
+        from .gds_write import write_saige_output
+        write_saige_output(fn, ans, sample_id or [], res_compress)
+        return
     if re.search(r"\.(rda|RData)$", fn, re.I):
         raw = b"RDX2\n" + _HEADER + _pairlist([(".res", _data_frame(ans))])
     elif re.search(r"\.rds$", fn, re.I):

@@ -103,8 +103,54 @@ def test_result_writers_roundtrip(tmp_path):
         assert list(r["chr"]) == ans["chr"] and np.array_equal(np.asarray(r["converged"]), ans["converged"])
     with pytest.raises(ValueError, match="Unknown format"):
         save_result(ans, str(tmp_path / "res.txt"))
-    with pytest.raises(NotImplementedError):
-        save_result(ans, str(tmp_path / "res.gds"))
+    # GDS SAIGE_OUTPUT container (R/assoc_single.r:243-286), read back with the GDS decoder
+    from saigegds_amd.gds import GdsFile
+    full = dict(ans)
+    full.update({"rs.id": [f"rs{i}" for i in range(len(z["id"]))], "beta": z["beta"], "p.norm": z["p_norm"]})
+    for cm in ("LZMA", "none"):
+        fn = str(tmp_path / f"res_{cm}.gds")
+        save_result(full, fn, cm, sample_id=[f"s{i}" for i in range(7)])
+        g = GdsFile(fn)
+        # same nodes in the order the reference writes them
+        assert g.ls() == ["sample.id", "id", "chr", "rs.id", "AF.alt", "num", "beta", "pval", "p.norm", "converged"]
+        assert g.sample_id() == [f"s{i}" for i in range(7)]
+        assert list(g.read("chr")) == full["chr"] and list(g.read("rs.id")) == full["rs.id"]
+        for k in ("AF.alt", "beta", "pval", "p.norm"):
+            assert g.node(k).cls == "dFloat64" and np.array_equal(np.asarray(g.read(k)), full[k], equal_nan=True)
+        assert g.node("num").cls == "dInt32" and np.array_equal(np.asarray(g.read("num")), full["num"])
+        assert np.array_equal(np.asarray(g.read("converged")) == 1, full["converged"])
+        assert np.array_equal(g.read_rows("pval", 4000, 4100), full["pval"][4000:4100])     # through the block index
+        root = g.stream(g.root_id)
+        assert b"\nFileFormat\x0e\x0cSAIGE_OUTPUT" in root and b"\x07Version\x0e" in root
+        assert b"\tR.logical\x00" in g.stream(g.node("converged").block_id)
+
+
+@pytest.mark.reference
+def test_gds_writer_emits_the_reference_files_records():
+    """A node written by GdsWriter with the data of a node of the reference's own file is that node's
+    stream byte for byte (up to the stream id, the stored size and SeqArray's md5 attribute)."""
+    import tempfile
+    from saigegds_amd.gds import GdsFile
+    from saigegds_amd.gds_write import GdsWriter
+    g = GdsFile(REFERENCE + "/inst/extdata/assoc_100snp.gds")
+    with tempfile.TemporaryDirectory() as d:
+        w = GdsWriter(os.path.join(d, "t.gds"))
+        w.put_attr("FileFormat", "SEQ_ARRAY")
+        w.put_attr("FileVersion", "v1.0")
+        w.add("sample.id", g.sample_id())
+        w.add("position", np.asarray(g.read("position")))
+        w.close()
+        t = GdsFile(os.path.join(d, "t.gds"))
+        mine, ref = t.stream(t.node("sample.id").block_id), g.stream(g.node("sample.id").block_id)
+        k = ref.find(b"\x02\xc9FmP\xe0Q%\x04\x10") + 10 + 8       # PIPE_SIZE: raw size equal, stored size may differ
+        assert len(mine) == len(ref) and mine[:k] == ref[:k] and mine[k + 8:-19] == ref[k + 8:-19]
+        assert mine[-11:] == ref[-11:]                                  # attribute count record
+        mine, ref = t.stream(t.node("position").block_id), g.stream(g.node("position").block_id)
+        k = ref.find(b"\x02\xc9FmP\xe0Q%\x04\x10") + 10 + 8
+        assert mine[8:k] == ref[8:k]                                    # class, pipe, raw size (the reference's node has one more record: md5)
+        assert np.array_equal(t.read("position"), g.read("position")) and t.sample_id() == g.sample_id()
+        # root folder: directory records and the attribute block as SeqArray's own root has them
+        assert t.stream(t.root_id)[-46:] == g.stream(g.root_id)[-46:]
 
 
 def test_synthetic_generator_is_counter_based():
@@ -133,3 +179,77 @@ def test_formats_against_reference_files():
     assert not g2.has_genotype()
     ds = g2.dosage_real()
     assert ds.shape == (100, 1000) and set(np.unique(ds)) == {0.0, 1.0, 2.0}
+
+
+@pytest.mark.reference
+def test_gds_row_ranges_equal_whole_reads():
+    """Ranged reads through the LZMA_RA block index (what the streaming driver uses) give the same
+    bytes as decoding the whole node, across block borders and for sample subsets."""
+    from saigegds_amd.gds import GdsFile, unpack_dosage_2bit
+    g = GdsFile(REFERENCE + "/inst/extdata/grm1k_10k_snp.gds")
+    z = np.load(os.path.join(GOLDEN, "grm1k_10k_snp.npz"))
+    for lo, hi in ((0, 1), (4700, 4800), (4718, 4719), (9437, 9440), (9990, 10000), (0, 10000)):
+        assert np.array_equal(g.dosage_alt_packed_range(lo, hi), z["packed"][lo:hi]), (lo, hi)
+    sel = np.array([5, 3, 999, 0, 17])
+    got = unpack_dosage_2bit(g.dosage_alt_packed_range(4000, 5000, sel), 5)
+    assert np.array_equal(got, unpack_dosage_2bit(z["packed"][4000:5000], 1000)[:, sel])
+    assert np.array_equal(g.read_rows("position", 100, 250), np.asarray(g.read("position"))[100:250])
+    g2 = GdsFile(REFERENCE + "/inst/extdata/assoc_100snp.gds")
+    assert np.array_equal(g2.dosage_real_range("annotation/format/DS", 10, 37), g2.dosage_real()[10:37])
+
+
+def test_dosage_alt_counts_every_non_reference_allele():
+    """$dosage_alt of a site with alleles 0/1/2 stored in 2 bits: allele 2 counts as non-reference,
+    allele code 3 makes the sample missing (SeqArray's $dosage_alt, R/assoc_single.r:69-85)."""
+    from saigegds_amd.gds import GdsFile
+    lut = GdsFile._nibble_lut()
+
+    def byte(s0, s1):      # two samples' allele pairs in one byte of genotype/data
+        return s0[0] | (s0[1] << 2) | (s1[0] << 4) | (s1[1] << 6)
+    cases = {((0, 0), (0, 1)): (0, 1), ((1, 1), (0, 2)): (2, 1), ((2, 2), (1, 2)): (2, 2),
+             ((3, 1), (2, 0)): (3, 1), ((0, 3), (3, 3)): (3, 3)}
+    for (s0, s1), (d0, d1) in cases.items():
+        v = int(lut[byte(s0, s1)])
+        assert (v & 3, v >> 2) == (d0, d1), (s0, s1)
+
+
+def test_scan_blocks_runs_one_thread_per_gpu():
+    """The block loop of seqAssocGLMM_SPA with parallel = 2: two scanners work at the same time, every
+    block lands at its own offset, a failing block stops the scan with its error."""
+    import threading
+    import time
+    from saigegds_amd.assoc import scan_blocks
+    state = {"live": 0, "peak": 0, "made": []}
+    lock = threading.Lock()
+
+    class FakeScanner:
+        def __init__(self, d):
+            self.n, self.d = 7, d
+            state["made"].append(d)
+
+        def scan_2bit(self, blk):
+            with lock:
+                state["live"] += 1
+                state["peak"] = max(state["peak"], state["live"])
+            time.sleep(0.05)
+            with lock:
+                state["live"] -= 1
+            o = np.repeat(blk[:, :1].astype(np.float64), 8, axis=1)
+            return o, np.ones(blk.shape[0], np.uint8)
+
+        def close(self):
+            pass
+
+    m = 1050
+    blocks = [(o, min(m, o + 100)) for o in range(0, m, 100)]
+    out, valid = np.zeros((m, 8)), np.zeros(m, np.uint8)
+    scan_blocks(FakeScanner, 2, blocks, lambda lo, hi: (np.arange(lo, hi) % 251).astype(np.uint8)[:, None], True, out, valid)
+    assert sorted(state["made"]) == [0, 1] and state["peak"] == 2
+    assert valid.all() and np.array_equal(out[:, 0], np.arange(m) % 251)
+
+    def bad_read(lo, hi):
+        if lo == 300:
+            raise RuntimeError("decode failed")
+        return np.zeros((hi - lo, 1), np.uint8)
+    with pytest.raises(RuntimeError, match="decode failed"):
+        scan_blocks(FakeScanner, 2, blocks, bad_read, True, out, valid)
