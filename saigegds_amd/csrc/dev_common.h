@@ -278,27 +278,35 @@ __device__ __forceinline__ VarHead make_head(const DevModel &md, double AC, int 
 // Series SPA stage (kern_spa4.h): a flagged variant starts in tier A (short series) while the predicted
 // max_i |g_i t| is small: t ~ 1.5 x the first Newton point, |g_i| <= (2 + sum_k |c'_k| max_i |X_ik|) / sqrt(AC2).
 #define SPA4_TIER_X 0.45
-#define SPA4_EXACT_X 1.3         /* beyond this the series is not tried: straight to the exact kernel */
+#define SPA5_NNZ 16384           /* variants with at most this many carriers go to the per-variant kernels */
+#define SPA5_EXACT_X 1.2         /* ... and straight to the exact sweeps beyond this predicted max |g t| */
+// 0, 1: tiers A, B of the per-segment moments kernels;  2: per-variant kernel, series on the list;
+// 3: per-variant kernel, exact exp/log sweeps
 __device__ __forceinline__ int spa_tier(const DevModel &md, const SpaRec &r)
 {
 	double bmax = 0;
 	for (int k = 0; k < md.K; k++) bmax += fabs(r.c[k]) * md.Xabs[k];
 	const double t1 = fabs(r.S) * sqrt(r.AC2) / (sqrt(md.r) * r.var2);
 	const double x = 1.5 * t1 * (2.0 + bmax) / sqrt(r.AC2);
-	return (x <= SPA4_TIER_X) ? 0 : ((x <= SPA4_EXACT_X) ? 1 : 2);
+	// Few carriers: one workgroup builds the variant's list once (a pass per sample segment would be
+	// all overhead) and runs the series or, where that is hopeless, the exact sweeps on it.
+	if (r.nnz <= SPA5_NNZ) return (x <= SPA5_EXACT_X) ? 2 : 3;
+	return (x <= SPA4_TIER_X) ? 0 : 1;
 }
 
 // Record of a flagged variant into recs[]: tier A from slot 0 upwards (counters[0]), tier B from slot
-// btop - 1 downwards (counters[7]), the variants that go straight to the exact kernel from slot btop
-// upwards (counters[5]; their indices also onto the exact kernel's list fb_exact, counters[3]).
-// btop = 0: one range only.
-__device__ __forceinline__ void spa_push(const DevModel &md, SpaRec *recs, int *counters, int btop, int *fb_exact, const SpaRec &r)
+// btop - 1 downwards (counters[7]), the variants of the per-variant kernels from slot btop upwards
+// (counters[5]; their indices also onto the list of their kernel: fb_series / counters[3] or
+// fb_exact / counters[4]).  btop = 0: one range only.
+__device__ __forceinline__ void spa_push(const DevModel &md, SpaRec *recs, int *counters, int btop, int *fb_series,
+	int *fb_exact, const SpaRec &r)
 {
 	const int tier = btop > 0 ? spa_tier(md, r) : 0;
 	int slot;
-	if (tier == 2) {
+	if (tier >= 2) {
 		slot = btop + atomicAdd(&counters[5], 1);
-		fb_exact[atomicAdd(&counters[3], 1)] = slot;
+		if (tier == 2) fb_series[atomicAdd(&counters[3], 1)] = slot;
+		else fb_exact[atomicAdd(&counters[4], 1)] = slot;
 	} else {
 		slot = tier ? btop - 1 - atomicAdd(&counters[7], 1) : atomicAdd(&counters[0], 1);
 	}

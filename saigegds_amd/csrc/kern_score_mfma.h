@@ -313,7 +313,7 @@ __device__ __forceinline__ HiLo mf_limbs(const int *a, int nl = MF_NLIMB)
 template <int K>
 __global__ void __launch_bounds__(256)
 score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf,
-	SpaRec *__restrict__ recs, int *__restrict__ counters, int btop, int *__restrict__ fb_exact, double *__restrict__ out8,
+	SpaRec *__restrict__ recs, int *__restrict__ counters, int btop, int *__restrict__ fb_series, int *__restrict__ fb_exact, double *__restrict__ out8,
 	uint8_t *__restrict__ valid)
 {
 	constexpr int P = 2 * K + 2, CW = P - 1;     // score columns c' (K), e (K), s, w; column CW carries G^2
@@ -382,7 +382,7 @@ score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf
 		
 #pragma unroll
 		for (int k = 0; k < KMAX; k++) rr.c[k] = cbuf[k];
-		spa_push(md, recs, counters, btop, fb_exact, rr);
+		spa_push(md, recs, counters, btop, fb_series, fb_exact, rr);
 	}
 	atomicAdd(&counters[1], 1);
 }

@@ -154,11 +154,15 @@ __device__ __forceinline__ void cgf_terms(double g, double m, double t, double &
 }
 
 
-// samples per extraction segment for K covariates: rows of (K + 2) & ~1 doubles, a power of two
-// of them in 128 KiB of LDS, at most 4096
+// samples per segment of the SPA stage for K covariates: rows of (K + 2) & ~1 doubles, a power of two
+// of them in SPA_TAB_KB KiB of LDS
+#ifndef SPA_TAB_KB
+#define SPA_TAB_KB 128
+#endif
 __host__ __device__ constexpr int spa_seg(int K)
 {
 	const int row = ((K + 2) & ~1) * 8;
-	return row <= 32 ? 4096 : row <= 64 ? 2048 : row <= 128 ? 1024 : 512;
+	const int full = row <= 32 ? 4096 : row <= 64 ? 2048 : row <= 128 ? 1024 : 512;      // 128 KiB
+	return full * SPA_TAB_KB / 128;
 }
 

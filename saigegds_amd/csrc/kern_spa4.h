@@ -38,7 +38,9 @@
 //                 the cutoff exit (SPATest.cpp:319-321), both root searches (root_feed / root_step of
 //                 kern_spa2.h, fed from the series), tail probabilities, SE, the output row
 
+#ifndef SPA4_WAVES
 #define SPA4_WAVES 8
+#endif
 #define SPA4_NCA 12              /* cumulants carried for the variants of tier A (small g t: most carriers) */
 #define SPA4_NCB SPA4_NC         /* ... of tier B */
 #define SPA4_NSMAX (SPA4_NC + 5) /* partial sums per (variant, segment) of the wider tier */
@@ -529,20 +531,106 @@ __device__ __noinline__ void cgf_terms_rt(double g, double m, double t, bool wit
 // bytes of scratch per workgroup: (adj, mu) list + index list, N entries each
 __host__ __device__ inline size_t spa5_wg_bytes(int N) { return (((size_t)N + 63) & ~(size_t)63) * (16 + 4); }
 
-template <int K, int INPUT>
+// this thread's share of the cumulant sums over a variant's list (a call: the polynomial constants stay
+// out of the caller's registers)
+__device__ __noinline__ void spa5_cum_sweep(const double2 *__restrict__ glist, int nnz, double ts, double *kp_out)
+{
+	constexpr int NC = SPA4_NCB;
+	double kp[NC - 1];
+#pragma unroll
+	for (int a = 0; a < NC - 1; a++) kp[a] = 0;
+	for (int k = threadIdx.x; k < nnz; k += SPA5_BLOCK) {
+		const double2 gm = glist[k];
+		const double mui = gm.y;
+		spa4_cum_terms<NC>(gm.x * ts, mui * (1 - mui), 1 - 2 * mui, kp);
+		kp[NC - 2] = fmax(kp[NC - 2], fabs(gm.x));
+	}
+#pragma unroll
+	for (int a = 0; a < NC - 1; a++) kp_out[a] = kp[a];
+}
+
+// thread 0 of spa5_series: both root searches and the tail on the cumulant sums in arg[]
+__device__ __noinline__ int spa5_series_solve(const double *arg, const SpaRec *__restrict__ rec, double *__restrict__ out8)
+{
+	constexpr int NC = SPA4_NCB;
+	Spa4Series<NC> S;
+#pragma unroll
+	for (int a = 0; a < NC - 2; a++) S.kp[a] = arg[a];
+	S.k1 = arg[NC - 2]; S.k2 = arg[NC - 1]; S.ts = arg[NC]; S.gmax = arg[NC + 1];
+	const double xmax = arg[NC + 2], qtilde = arg[NC + 3], qinv = arg[NC + 4], NAmu = arg[NC + 5], NAsigma = arg[NC + 6];
+	const double pn_in = arg[NC + 7], Tstat = arg[NC + 8], var1 = arg[NC + 9];
+	RootState s1, s2;
+	if (!spa4_root(S, xmax, qtilde, NAmu, NAsigma, s1) || !spa4_root(S, xmax, qinv, NAmu, NAsigma, s2)) return 0;
+	double pval;
+	bool converged = true;
+	if (s1.converged && s2.converged) {
+		const double p1 = lugannani_rice(s1.root, s1.Kcur, s1.K2cur, qtilde, NAmu, NAsigma);
+		const double p2 = lugannani_rice(s2.root, s2.Kcur, s2.K2cur, qinv, NAmu, NAsigma);
+		pval = fabs(p1) + fabs(p2);
+		if (pval != 0 && pn_in / pval > 1000) pval = pn_in;   // SPATest.cpp:368-371
+	} else {
+		pval = pn_in;
+		converged = false;
+	}
+	const SpaRec rr = *rec;
+	spa_write_row(rr, Tstat, var1, pval, converged, out8);
+	return 1;
+}
+
+// The series on a variant's (adj, mu) list (spa5_kernel): one sweep for the cumulant sums, then thread 0
+// runs both root searches and the tail on them.  Returns (to every thread) whether the row was written;
+// false = some evaluation point lies outside what sixteen cumulants cover: the caller goes on with the
+// exact sweeps.  sh: (NC - 1) * (SPA5_BLOCK / 64) + NC + 16 doubles of shared memory.
+__device__ __forceinline__ bool spa5_series(const double2 *__restrict__ glist, int nnz, double ts, double xmax,
+	double k1, double k2, double qtilde, double qinv, double NAmu, double NAsigma, double pn_in,
+	double Tstat, double var1, const SpaRec *__restrict__ rec, double *__restrict__ out8, double *sh, int *sh_flag)
+{
+	constexpr int NC = SPA4_NCB;
+	double kp[NC - 1];                 // kappa'_3..NC, and max |adj| in the last slot
+	spa5_cum_sweep(glist, nnz, ts, kp);
+	// sums of the cumulants; the maximum through the same tree would be wrong, so it goes apart
+	double gmax = kp[NC - 2];
+	kp[NC - 2] = 0;
+	block_sum<NC - 1, SPA5_BLOCK>(kp, sh);
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o, WAVE));
+	if ((threadIdx.x & (WAVE - 1)) == 0) sh[threadIdx.x / WAVE] = gmax;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 0; w < SPA5_BLOCK / WAVE; w++) gmax = fmax(gmax, sh[w]);
+		// the scalar part as a call: its registers (two root searches on sixteen cumulants) stay out of
+		// the workgroup's budget
+		double *arg = sh + SPA5_BLOCK / WAVE;
+#pragma unroll
+		for (int a = 0; a < NC - 2; a++) arg[a] = kp[a];
+		arg[NC - 2] = k1; arg[NC - 1] = k2; arg[NC] = ts; arg[NC + 1] = gmax; arg[NC + 2] = xmax;
+		arg[NC + 3] = qtilde; arg[NC + 4] = qinv; arg[NC + 5] = NAmu; arg[NC + 6] = NAsigma;
+		arg[NC + 7] = pn_in; arg[NC + 8] = Tstat; arg[NC + 9] = var1;
+		*sh_flag = spa5_series_solve(arg, rec, out8);
+	}
+	__syncthreads();
+	const bool done = *sh_flag != 0;
+	__syncthreads();                   // sh and the flag are free again
+	return done;
+}
+
+// MODE 0: the series on the list; variants it does not cover are appended to `todo_next` (counters[4]).
+// MODE 1: the exact sweeps (over that list).
+template <int K, int INPUT, int MODE>
 __global__ void __launch_bounds__(SPA5_BLOCK)
 spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec *__restrict__ recs,
-	int *__restrict__ counters, const int *__restrict__ todo, int *__restrict__ cursor,
-	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8, int force_dense)
+	int *__restrict__ counters, const int *__restrict__ todo, int *__restrict__ todo_next, int *__restrict__ cursor,
+	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8, int force_dense, int force_exact)
 {
 	constexpr int KP = (K + 2) & ~1, NW = SPA5_BLOCK / WAVE;
-	__shared__ double sh[6 * NW];
+	__shared__ double sh[SPA4_NCB * NW + SPA4_NCB + 16];
+	__shared__ int sh_flag;
 	__shared__ int shi[NW];
 	__shared__ int sh_vi;
 	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
 	double2 *glist = reinterpret_cast<double2 *>(scratch + (size_t)blockIdx.x * spa5_wg_bytes(N));
 	uint32_t *ilist = reinterpret_cast<uint32_t *>(glist + (((size_t)N + 63) & ~(size_t)63));
-	const int ntodo = counters[3];
+	const int ntodo = counters[MODE == 0 ? 3 : 4];
 	// pieces of 64 samples: a uint4 of a packed row, or 64 dosages
 	const int nvec = INPUT == IN_2BIT ? (int)(min((size_t)((N + 63) >> 6) * 16, bpv) / 16) : (N + 63) >> 6;
 	const int per = ((nvec + NW - 1) / NW + WAVE - 1) & ~(WAVE - 1);          // pieces per wave, whole wave steps
@@ -694,6 +782,14 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 				continue;
 			}
 			const double NAmu = m1 - a6[4], NAsigma = var2 - a6[5];
+			if (MODE == 0) {
+				// the series: one sweep over the list instead of one per Newton step
+				if (force_exact || !spa5_series(glist, nnz, r.tscale, md.spa_xmax, a6[4], a6[5], qtilde, qinv, NAmu, NAsigma,
+						pn_in, Tstat, var1, &recs[v], out8, sh, &sh_flag)) {
+					if (tid == 0) todo_next[atomicAdd(&counters[4], 1)] = v;     // on to the exact exp/log sweeps
+				}
+				continue;
+			}
 			RootState s1, s2;
 			root_begin(s1, qtilde, L, U);
 			root_begin(s2, qinv, L, U);

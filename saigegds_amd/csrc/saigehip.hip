@@ -79,7 +79,8 @@ struct sgx_handle {
 	// per-call workspace
 	SpaRec *recs = nullptr; size_t recs_cap = 0;
 	int *fallback = nullptr;          // rec indices that need the exact dense pass
-	int *fb_spa2 = nullptr;           // rec indices left to the per-workgroup SPA kernel
+	int *fb_spa2 = nullptr;           // rec indices for the per-variant kernel (series on the variant's list)
+	int *fb_x2 = nullptr;             // ... of those, the ones that need the exact sweeps
 	int nseg = 0;                     // sample segments of the SPA stage
 	bool force_dense = false;         // test hook: every SPA variant takes the exact dense pass
 	// series SPA stage (kern_spa4.h)
@@ -261,7 +262,7 @@ static int alloc_workspace(sgx_handle *h)
 	if (!h->md.quant) {
 		h->nwg5 = h->n_cu * 2;
 		HIPCHK(hipMalloc((void **)&h->scr5, (size_t)h->nwg5 * spa5_wg_bytes(N)));
-		HIPCHK(hipMalloc((void **)&h->cur5, sizeof(int)));
+		HIPCHK(hipMalloc((void **)&h->cur5, 2 * sizeof(int)));
 	}
 	return SGX_OK;
 }
@@ -472,7 +473,7 @@ extern "C" void sgx_free(sgx_handle *h)
 		(void)hipFree(h->dF); (void)hipFree(h->dX); (void)hipFree(h->dy);
 		(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->dFl);
 	}
-	(void)hipFree(h->fallback); (void)hipFree(h->fb_spa2);
+	(void)hipFree(h->fallback); (void)hipFree(h->fb_spa2); (void)hipFree(h->fb_x2);
 	(void)hipFree(h->mf_acc); (void)hipFree(h->seg4); (void)hipFree(h->scr5); (void)hipFree(h->cur5);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
 	for (int b = 0; b < 2; b++) {
@@ -505,6 +506,9 @@ static int ensure_recs(sgx_handle *h, size_t n)
 		h->fb_spa2 = nullptr;
 		h->nseg = (h->md.N + spa_seg(h->md.K) - 1) / spa_seg(h->md.K);
 		HIPCHK(hipMalloc((void **)&h->fb_spa2, n * sizeof(int)));
+		if (h->fb_x2) HIPCHK(hipFree(h->fb_x2));
+		h->fb_x2 = nullptr;
+		HIPCHK(hipMalloc((void **)&h->fb_x2, n * sizeof(int)));
 		if (h->seg4) HIPCHK(hipFree(h->seg4));
 		h->seg4 = nullptr;
 		h->vcap4 = (int)std::min<size_t>(n, 32768);       // flagged variants per round of the series SPA stage
@@ -547,7 +551,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	constexpr int SB = 256, PB = 512;
 	hipStream_t st = h->stream;
 	HIPCHK(hipMemsetAsync(h->counters, 0, 8 * sizeof(int), st));
-	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, sizeof(int), st));
+	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 2 * sizeof(int), st));
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	const bool use_mf = (INPUT == IN_2BIT) && h->mf_ok && !h->force_v1;
 	if (use_mf) {
@@ -577,7 +581,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		switch (md.K) {
 #define ECASE(KK) case KK:                                                                     \
 	hipLaunchKernelGGL((score_mfma_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), \
-		0, st, (int)M, md, ep, h->mf_acc, h->recs, h->counters, md.quant ? 0 : (int)(2 * M), h->fb_spa2, out8, valid); break;
+		0, st, (int)M, md, ep, h->mf_acc, h->recs, h->counters, md.quant ? 0 : (int)(2 * M), h->fb_spa2, h->fb_x2, out8, valid); break;
 		FOR_EACH_K(ECASE)
 #undef ECASE
 		default: return fail(SGX_EINVAL, "MFMA score path: unsupported K=%d", md.K);
@@ -636,12 +640,12 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 #define MOMENTS(KK, NCX, TIER, RD)                                                               \
 	do {                                                                                         \
 		if (INPUT == IN_2BIT)                                                                    \
-			hipLaunchKernelGGL((spa4_moments<KK, NCX>), dim3((unsigned)h->n_cu),                 \
+			hipLaunchKernelGGL((spa4_moments<KK, NCX>), dim3((unsigned)(h->n_cu * (8 / SPA4_WAVES))), \
 				dim3(WAVE * SPA4_WAVES), fl, st, (const uint8_t *)rows, row_bytes, md, h->nseg,  \
 				TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl); \
 		else                                                                                     \
 			hipLaunchKernelGGL((spa4_moments_ds<KK, NCX, (INPUT == IN_2BIT ? IN_U8 : INPUT)>),   \
-				dim3((unsigned)h->n_cu), dim3(WAVE * SPA4_WAVES), fl, st, rows, row_bytes, md,   \
+				dim3((unsigned)(h->n_cu * (8 / SPA4_WAVES))), dim3(WAVE * SPA4_WAVES), fl, st, rows, row_bytes, md, \
 				h->nseg, TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4);  \
 		hipLaunchKernelGGL((spa4_solve<KK, NCX>), gsolve, dim3(256), 0, st, md, h->nseg, TIER,   \
 			btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->fallback,         \
@@ -673,9 +677,12 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCB, 1, rd);                \
 			/* what the series does not cover: exact exp/log sums, one workgroup per variant; \
 			   then the exact dense g_pos / g_neg pass */                                    \
-			hipLaunchKernelGGL((spa5_kernel<KK, INPUT>), dim3((unsigned)h->nwg5), dim3(SPA5_BLOCK), \
-				0, st, rows, row_bytes, md, h->recs, h->counters, h->fb_spa2, h->cur5,       \
-				h->fallback, h->scr5, out8, h->force_dense ? 1 : 0);                         \
+			hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 0>), dim3((unsigned)h->nwg5), dim3(SPA5_BLOCK), \
+				0, st, rows, row_bytes, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
+				h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0); \
+			hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 1>), dim3((unsigned)h->nwg5), dim3(SPA5_BLOCK), \
+				0, st, rows, row_bytes, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
+				h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0); \
 			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
 				row_bytes, md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
 				h->scratch_stride, out8);                                                    \
@@ -686,7 +693,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 #undef MOMENTS
 		}
 		HIPCHK(hipGetLastError());
-		h->stats.spa_launches = (h->force_v1 && INPUT != IN_2BIT) ? 1u : (uint32_t)(4 * ((M + h->vcap4 - 1) / h->vcap4) + 2);
+		h->stats.spa_launches = (h->force_v1 && INPUT != IN_2BIT) ? 1u : (uint32_t)(4 * ((M + h->vcap4 - 1) / h->vcap4) + 3);
 	}
 	HIPCHK(hipEventRecord(h->ev[2], st));
 	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -740,7 +747,7 @@ static int sync_lane(sgx_handle *h)
 		h->stats.n_spa = (uint64_t)(h->h_counters[0] + h->h_counters[7] - h->h_counters[6] + h->h_counters[5]);   // the tiers (handed-on copies once) + straight to exact
 		h->stats.n_valid = (uint64_t)h->h_counters[1];
 		h->stats.n_spa_dense = (uint64_t)h->h_counters[2];
-		h->stats.n_spa_slow = (uint64_t)h->h_counters[3];
+		h->stats.n_spa_slow = (uint64_t)h->h_counters[4];
 		float a = 0, b = 0, c = 0;
 		(void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
 		(void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
