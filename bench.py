@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--pool-gb", type=float, default=120.0, help="max HBM for resident genotypes")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (wall, all cores); 0 = skip")
     ap.add_argument("--seed", type=int, default=20260)
+    ap.add_argument("--host-variants", type=int, default=20000,
+                    help="variants of one block pushed through the host-buffer entry point (PCIe-inclusive rate); 0 = skip")
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
                     help="library streams per GPU: with 2 the SPA stage of one step runs under the score stage of the next")
     args = ap.parse_args()
@@ -313,6 +315,28 @@ def main():
                "gpu_vs_longdouble_max_rel": float(np.nanmax(e_gpu)),
                "oracle_vs_longdouble_max_rel": float(np.nanmax(e_orc))}
 
+    # ---- PCIe-inclusive rate of the host-buffer entry point (rank 0, N=1 only; never `value`) -------
+    host_path = None
+    if rank == 0 and world == 1 and args.host_variants > 0:
+        from saigegds_amd._lib import PinnedBuffer
+        nh = min(block, args.host_variants)
+        b0 = warmup % pool
+        sc.set_option("lanes", 1)
+        with PinnedBuffer((nh, bpv)) as pin:
+            pin.array[:] = packed[b0, :nh].cpu().numpy()
+            sc.scan_2bit(pin.array[:1000])
+            best = float("inf")
+            for _ in range(2):
+                t = time.perf_counter()
+                ho, hv = sc.scan_2bit(pin.array)
+                best = min(best, time.perf_counter() - t)
+            same = bool(np.array_equal(hv, valid[b0, :nh].cpu().numpy()) and
+                        np.array_equal(np.nan_to_num(ho, nan=-7.0), np.nan_to_num(out[b0, :nh].cpu().numpy(), nan=-7.0)))
+        pcie = 63.0     # GB/s, PCIe Gen5 x16 (MI355X_MICROARCH.md)
+        host_path = {"value": round(nh / best, 1), "unit": "variants/s", "entry": "sgx_scan_2bit (pinned host block in, table out)",
+                     "variants": nh, "GBps_host_to_result": round(nh * (bpv + 65) / best / 1e9, 2), "pcie_peak_GBps": pcie,
+                     "frac_of_pcie": round(nh * (bpv + 65) / best / 1e9 / pcie, 4), "same_table_as_resident_scan": same}
+
     if rank == 0:
         line = {
             "metric": "variants/sec seqAssocGLMM_SPA at N=430K; achieved HBM GB/s vs roofline",
@@ -329,7 +353,7 @@ def main():
                 "frac_spa": round(n_spa / max(1, nv_tot), 5), "frac_valid": round(n_valid / max(1, nv_tot), 5),
                 "gen_seconds": round(t_gen, 2),
             },
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path,
         }
         print(json.dumps(line), flush=True)
     sc.close()

@@ -516,7 +516,7 @@ spa4_solve(DevModel md, int nseg, int tier, int btop, int v0, int vcap, SpaRec *
 #define SPA5_BIG 2048            /* lists longer than this are started first (they set the kernel's tail) */
 
 // K1, K2 (SPATest.cpp:64,79-80) and Korg (:49) terms of one carrier at t; the Korg term switched at run time (workgroup-uniform)
-__device__ __noinline__ void cgf_terms_rt(double g, double m, double t, bool with_k, double &k1, double &k2, double &k0)
+__device__ __forceinline__ void cgf_terms_rt(double g, double m, double t, bool with_k, double &k1, double &k2, double &k0)
 {
 	const double om = 1 - m, mg = m * g, c2 = om * mg * g;
 	const double e = fast_exp(-g * t);
@@ -620,9 +620,12 @@ template <int K, int INPUT, int MODE>
 __global__ void __launch_bounds__(SPA5_BLOCK)
 spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec *__restrict__ recs,
 	int *__restrict__ counters, const int *__restrict__ todo, int *__restrict__ todo_next, int *__restrict__ cursor,
-	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8, int force_dense, int force_exact)
+	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8, int force_dense, int force_exact,
+	size_t lds_row_bytes)
 {
 	constexpr int KP = (K + 2) & ~1, NW = SPA5_BLOCK / WAVE;
+	extern __shared__ __attribute__((aligned(16))) uint8_t fill_smem[];
+	uint4 *rows_lds = reinterpret_cast<uint4 *>(fill_smem);
 	__shared__ double sh[SPA4_NCB * NW + SPA4_NCB + 16];
 	__shared__ int sh_flag;
 	__shared__ int shi[NW];
@@ -652,11 +655,25 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 		// ---- index list: sample | code << 30, ascending.  Wave w owns pieces [w per, (w+1) per).
 		// ww/z: codes and carrier bits of piece p (2-bit rows); dosage rows: z[0], z[1] = a 64-bit mask of
 		// the piece's non-zero dosages, bit s = sample 64 p + s
+		// 2-bit rows that fit go through LDS: one streaming copy with many loads in flight instead of two
+		// latency-bound passes over global memory (rows_lds: dynamic shared memory of nvec uint4, or none)
+		const bool staged = INPUT == IN_2BIT && lds_row_bytes >= (size_t)nvec * 16;
+		if (staged) {
+			constexpr int UN = 8;
+			for (int p0 = tid; p0 < nvec; p0 += UN * SPA5_BLOCK) {
+				uint4 t[UN];
+#pragma unroll
+				for (int j = 0; j < UN; j++) { const int p = p0 + j * SPA5_BLOCK; t[j] = p < nvec ? row[p] : make_uint4(0u, 0u, 0u, 0u); }
+#pragma unroll
+				for (int j = 0; j < UN; j++) { const int p = p0 + j * SPA5_BLOCK; if (p < nvec) rows_lds[p] = t[j]; }
+			}
+			__syncthreads();
+		}
 		auto masks = [&](int p, uint32_t (&ww)[4], uint32_t (&z)[4]) -> int {
 			int cnt = 0;
 			if (INPUT == IN_2BIT) {
 				uint4 w = make_uint4(0u, 0u, 0u, 0u);
-				if (p < nvec) w = row[p];
+				if (p < nvec) w = staged ? rows_lds[p] : row[p];
 				ww[0] = w.x; ww[1] = w.y; ww[2] = w.z; ww[3] = w.w;
 #pragma unroll
 				for (int k = 0; k < 4; k++) { z[k] = nz_fields((ww[k] ^ zx) & keep_mask(N - p * 64 - 16 * k)); cnt += __popc(z[k]); }
@@ -724,7 +741,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 #pragma unroll
 		for (int a = 0; a < K; a++) c[a] = r.c[a];
 		double a6[6] = {0, 0, 0, 0, 0, 0};
-		for (int k0 = tid; k0 < nnz; k0 += 2 * SPA5_BLOCK) {
+		for (int k0 = tid; k0 < ((force_exact & 128) ? 0 : nnz); k0 += 2 * SPA5_BLOCK) {
 			uint32_t e[2];
 			double xv[2][KP];
 #pragma unroll
@@ -784,7 +801,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			const double NAmu = m1 - a6[4], NAsigma = var2 - a6[5];
 			if (MODE == 0) {
 				// the series: one sweep over the list instead of one per Newton step
-				if (force_exact || !spa5_series(glist, nnz, r.tscale, md.spa_xmax, a6[4], a6[5], qtilde, qinv, NAmu, NAsigma,
+				if ((force_exact & 1) || !spa5_series(glist, nnz, r.tscale, md.spa_xmax, a6[4], a6[5], qtilde, qinv, NAmu, NAsigma,
 						pn_in, Tstat, var1, &recs[v], out8, sh, &sh_flag)) {
 					if (tid == 0) todo_next[atomicAdd(&counters[4], 1)] = v;     // on to the exact exp/log sweeps
 				}
@@ -799,19 +816,16 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			auto sweep = [&](bool a1, bool a2, bool k1w, bool k2w, double t1, double t2, double (&sv)[6]) {
 #pragma unroll
 				for (int a = 0; a < 6; a++) sv[a] = 0;
-				for (int k0 = tid; k0 < nnz; k0 += 2 * SPA5_BLOCK) {
-					double2 gm[2];
-#pragma unroll
-					for (int j = 0; j < 2; j++) gm[j] = (k0 + j * SPA5_BLOCK < nnz) ? glist[k0 + j * SPA5_BLOCK] : make_double2(0.0, 0.5);   // g = 0 adds exactly 0
-#pragma unroll
-					for (int j = 0; j < 2; j++) {
-						if (a1) cgf_terms_rt(gm[j].x, gm[j].y, t1, k1w, sv[0], sv[1], sv[2]);
-						if (a2) cgf_terms_rt(gm[j].x, gm[j].y, t2, k2w, sv[3], sv[4], sv[5]);
-					}
+				double2 gn = tid < nnz ? glist[tid] : make_double2(0.0, 0.5);            // g = 0 adds exactly 0
+				for (int k0 = tid; k0 < nnz; k0 += SPA5_BLOCK) {
+					const double2 gm = gn;
+					if (k0 + SPA5_BLOCK < nnz) gn = glist[k0 + SPA5_BLOCK];              // one step ahead
+					if (a1) cgf_terms_rt(gm.x, gm.y, t1, k1w, sv[0], sv[1], sv[2]);
+					if (a2) cgf_terms_rt(gm.x, gm.y, t2, k2w, sv[3], sv[4], sv[5]);
 				}
 				block_sum<6, SPA5_BLOCK>(sv, sh);
 			};
-			while (s1.active || s2.active) {
+			while ((s1.active || s2.active) && !(force_exact & 64)) {
 				const bool a1 = s1.active, a2 = s2.active, k1w = s1.want_k, k2w = s2.want_k;
 				double sv[6];
 				sweep(a1, a2, k1w, k2w, s1.tnew, s2.tnew, sv);

@@ -86,6 +86,7 @@ struct sgx_handle {
 	// series SPA stage (kern_spa4.h)
 	double *seg4 = nullptr;           // [nseg][NC + 5][vcap4] partial sums of one round of flagged variants
 	int vcap4 = 0, nround4 = 0;
+	bool spa5_attr_set[3] = {false, false, false};
 	bool mom_attr_set[3] = {false, false, false};   // per input type: the moments kernels' dynamic LDS size has been raised
 	uint8_t *scr5 = nullptr; int *cur5 = nullptr; int nwg5 = 0;   // spa5_kernel: per-workgroup lists, queue cursor
 	int spa_abl = 0;                  // timing experiments (wrong results)
@@ -677,12 +678,22 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCB, 1, rd);                \
 			/* what the series does not cover: exact exp/log sums, one workgroup per variant; \
 			   then the exact dense g_pos / g_neg pass */                                    \
+			/* a packed row in LDS when it fits beside the kernel's static shared memory */  \
+			const size_t rowb5 = (size_t)((md.N + 63) / 64) * 16;                            \
+			const size_t l5 = (INPUT == IN_2BIT && rowb5 <= 120 * 1024) ? rowb5 : 0;         \
+			if (l5 > 48 * 1024 && !h->spa5_attr_set[INPUT]) {                                \
+				HIPCHK(hipFuncSetAttribute((const void *)spa5_kernel<KK, INPUT, 0>,          \
+					hipFuncAttributeMaxDynamicSharedMemorySize, (int)l5));                   \
+				HIPCHK(hipFuncSetAttribute((const void *)spa5_kernel<KK, INPUT, 1>,          \
+					hipFuncAttributeMaxDynamicSharedMemorySize, (int)l5));                   \
+				h->spa5_attr_set[INPUT] = true;                                              \
+			}                                                                                \
 			hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 0>), dim3((unsigned)h->nwg5), dim3(SPA5_BLOCK), \
-				0, st, rows, row_bytes, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
-				h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0); \
+				l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
+				h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, (h->force_exact ? 1 : 0) | (h->spa_abl & ~1), l5); \
 			hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 1>), dim3((unsigned)h->nwg5), dim3(SPA5_BLOCK), \
-				0, st, rows, row_bytes, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
-				h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0); \
+				l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
+				h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, (h->force_exact ? 1 : 0) | (h->spa_abl & ~1), l5); \
 			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
 				row_bytes, md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
 				h->scratch_stride, out8);                                                    \
