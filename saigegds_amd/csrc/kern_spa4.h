@@ -118,10 +118,13 @@ __device__ __forceinline__ int wave_reduce_scatter(double (&x)[V], int lane)
 
 #define SPA4_VPER 128            /* flagged variants whose parameters a workgroup holds in LDS at a time */
 
-// dynamic LDS of spa4_moments<K>: the segment's table + the parameter slice
+// entries of a wave's leftover queue
+__host__ __device__ constexpr int spa4_qcap(int K) { return spa_seg(K) / 2 < 1024 ? spa_seg(K) / 2 : 1024; }
+
+// dynamic LDS of spa4_moments<K>: the segment's table + the parameter slice + a queue per wave
 __host__ __device__ constexpr size_t spa4_lds_bytes(int K)
 {
-	return (size_t)spa_seg(K) * ((K + 2) & ~1) * 8 + (size_t)SPA4_VPER * (8 + 8 * (K + 6));
+	return (size_t)spa_seg(K) * ((K + 2) & ~1) * 8 + (size_t)SPA4_VPER * (8 + 8 * (K + 6)) + (size_t)SPA4_WAVES * spa4_qcap(K) * 2;
 }
 
 // The flagged variants of a call sit in recs[] in two ranges: tier A from slot 0 upwards (counters[0]
@@ -145,6 +148,7 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 	double *pd = tab + (size_t)SEG * KP;                                                  // [K + 6][VPER]: inv, ts, c[K], lut[4]
 	int *pj = reinterpret_cast<int *>(pd + (size_t)(K + 6) * SPA4_VPER);                 // [VPER] row, [VPER] flip mask
 	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	uint16_t *q = reinterpret_cast<uint16_t *>(pj + 2 * SPA4_VPER) + wid * spa4_qcap(K);      // this wave's queue: sample in the segment | code << 14
 	const int nflag = min(counters[tier ? 7 : 0] - v0, vcap);
 	if (nflag <= 0) return;
 	// the (segment, slice) items in segment-major order, an equal contiguous share per workgroup:
@@ -251,15 +255,65 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 				gmax = fmax(gmax, fabs(adj));
 				if (!(abl & 1)) spa4_cum_terms<NC>(adj * ts, u, 1 - 2 * mui, &acc[6]);
 			};
+			// A lane owns 64 samples, so the lanes' carrier counts differ (binomial): walking them in
+			// lock step to the largest count would leave ~40 % of the lane-steps empty.  Instead: T =
+			// ceil(mean count) lock-step rounds, then whatever the busier lanes have left goes through
+			// the wave's LDS queue and is shared out evenly, 64 carriers a round.
+			const int T = (wave_sum_i(__popc(lo) + __popc(hi)) + WAVE - 1) / WAVE;
 			Car ca, cb;
 			fetch(ca);
-			for (;;) {
-				if (!__ballot(ca.ok)) break;
-				fetch(cb);
+			for (int it = 0; it < T; it += 2) {
+				if (it + 1 < T) fetch(cb); else cb.ok = false;
 				if (ca.ok) work(ca);
-				if (!__ballot(cb.ok)) break;
-				fetch(ca);
+				if (it + 2 < T) fetch(ca); else ca.ok = false;
 				if (cb.ok) work(cb);
+			}
+			if (__ballot((lo | hi) != 0)) {
+				const int rem = __popc(lo) + __popc(hi);
+				int incl = rem;
+#pragma unroll
+				for (int o = 1; o < WAVE; o <<= 1) {
+					const int up = __shfl_up(incl, o, WAVE);
+					if (lane >= o) incl += up;
+				}
+				const int nq = min(__shfl(incl, WAVE - 1, WAVE), spa4_qcap(K));
+				int o2 = incl - rem;
+				while ((lo | hi) != 0 && o2 < spa4_qcap(K)) {
+					const bool inlo = lo != 0;
+					const int b = __ffs(inlo ? lo : hi) - 1;
+					if (inlo) lo &= lo - 1; else hi &= hi - 1;
+					const int dwi = (inlo ? 0 : 2) + (b & 1), sid = b >> 1;
+					const uint32_t wsel = dwi == 0 ? wd0 : dwi == 1 ? wd1 : dwi == 2 ? wd2 : wd3;
+					q[o2++] = (uint16_t)((lane * LDW + dwi) * 16 + sid) | (uint16_t)(((wsel >> (2 * sid)) & 3u) << 14);
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own LDS writes, in order
+				__builtin_amdgcn_wave_barrier();
+				auto fetch_q = [&](Car &cr, int k) {
+					cr.ok = k < nq;
+					if (cr.ok) {
+						const uint32_t e = q[k];
+						const double *x = tab + (size_t)(e & 0x3FFFu) * KP;
+#pragma unroll
+						for (int a = 0; a <= K; a++) cr.x[a] = x[a];
+						cr.G = lut[(e >> 14) * SPA4_VPER];
+					}
+				};
+				fetch_q(ca, lane);
+				for (int k = lane; k < nq; k += 2 * WAVE) {
+					fetch_q(cb, k + WAVE);
+					if (ca.ok) work(ca);
+					fetch_q(ca, k + 2 * WAVE);
+					if (cb.ok) work(cb);
+				}
+				__builtin_amdgcn_wave_barrier();      // queue reads stay before the next variant's writes
+				// (more left than the queue holds: a segment of near-complete carriers behind a very
+				// uneven start -- finish in lock step)
+				fetch(ca);
+				while (__ballot(ca.ok)) {
+					fetch(cb);
+					if (ca.ok) work(ca);
+					ca = cb;
+				}
 			}
 			const int idx = wave_reduce_scatter(acc, lane);
 #pragma unroll
