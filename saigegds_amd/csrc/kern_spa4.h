@@ -683,7 +683,8 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 	__shared__ double sh[SPA4_NCB * NW + SPA4_NCB + 16];
 	__shared__ int sh_flag;
 	__shared__ int shi[NW];
-	__shared__ int sh_vi;
+	__shared__ int sh_vi, sh_v;
+	__shared__ SpaRec sh_rec;
 	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
 	double2 *glist = reinterpret_cast<double2 *>(scratch + (size_t)blockIdx.x * spa5_wg_bytes(N));
 	uint32_t *ilist = reinterpret_cast<uint32_t *>(glist + (((size_t)N + 63) & ~(size_t)63));
@@ -693,15 +694,28 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 	const int per = ((nvec + NW - 1) / NW + WAVE - 1) & ~(WAVE - 1);          // pieces per wave, whole wave steps
 	for (;;) {
 		__syncthreads();                         // sh_vi, shi and the lists of the previous variant are free
-		if (tid == 0) sh_vi = atomicAdd(cursor, 1);
+		// wave 0 takes the next variant off the queue and its record into LDS (one coalesced read; the
+		// record's fields are then a few cycles away instead of a global latency each).  Two rounds
+		// over the list: the long lists first, then the short ones.
+		if (tid < WAVE) {
+			int vi0 = 0;
+			if (tid == 0) vi0 = atomicAdd(cursor, 1);
+			vi0 = __builtin_amdgcn_readfirstlane(vi0);
+			int v0 = -1;
+			if (vi0 < 2 * ntodo) {
+				v0 = todo[vi0 < ntodo ? vi0 : vi0 - ntodo];
+				const double *src = reinterpret_cast<const double *>(recs + v0);
+				for (int i = tid; i < (int)(sizeof(SpaRec) / 8); i += WAVE) reinterpret_cast<double *>(&sh_rec)[i] = src[i];
+			}
+			if (tid == 0) { sh_vi = vi0; sh_v = v0; }
+		}
 		__syncthreads();
 		const int vi = sh_vi;
 		if (vi >= 2 * ntodo) break;
-		// two rounds over the list: the long lists first, then the short ones
 		const bool big_round = vi < ntodo;
-		const int v = todo[big_round ? vi : vi - ntodo];
-		if ((recs[v].nnz > SPA5_BIG) != big_round) continue;
-		const SpaRec &r = recs[v];               // fields are read where they are used
+		const int v = sh_v;
+		const SpaRec &r = sh_rec;
+		if ((r.nnz > SPA5_BIG) != big_round) continue;
 		const uint8_t *rowb = reinterpret_cast<const uint8_t *>(rows) + (size_t)r.j * bpv;
 		const uint4 *row = reinterpret_cast<const uint4 *>(rowb);
 		const uint32_t zx = r.minus ? 0xAAAAAAAAu : 0u;
@@ -856,7 +870,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			if (MODE == 0) {
 				// the series: one sweep over the list instead of one per Newton step
 				if ((force_exact & 1) || !spa5_series(glist, nnz, r.tscale, md.spa_xmax, a6[4], a6[5], qtilde, qinv, NAmu, NAsigma,
-						pn_in, Tstat, var1, &recs[v], out8, sh, &sh_flag)) {
+						pn_in, Tstat, var1, &sh_rec, out8, sh, &sh_flag)) {
 					if (tid == 0) todo_next[atomicAdd(&counters[4], 1)] = v;     // on to the exact exp/log sweeps
 				}
 				continue;
@@ -903,6 +917,6 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 				converged = false;
 			}
 		}
-		if (tid == 0) { const SpaRec rr = recs[v]; spa_write_row(rr, Tstat, var1, pval, converged, out8); }
+		if (tid == 0) spa_write_row(r, Tstat, var1, pval, converged, out8);
 	}
 }
