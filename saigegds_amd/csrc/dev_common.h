@@ -282,26 +282,30 @@ __device__ __forceinline__ VarHead make_head(const DevModel &md, double AC, int 
 #define SPA5_EXACT_X 1.2         /* ... and straight to the exact sweeps beyond this predicted max |g t| */
 // 0, 1: tiers A, B of the per-segment moments kernels;  2: per-variant kernel, series on the list;
 // 3: per-variant kernel, exact exp/log sweeps
-__device__ __forceinline__ int spa_tier(const DevModel &md, const SpaRec &r)
+template <int K>
+__device__ __forceinline__ int spa_tier(const DevModel &md, int nnz, double S, double var2, double AC2, const double (&c)[KMAX])
 {
 	double bmax = 0;
-	for (int k = 0; k < md.K; k++) bmax += fabs(r.c[k]) * md.Xabs[k];
-	const double t1 = fabs(r.S) * sqrt(r.AC2) / (sqrt(md.r) * r.var2);
-	const double x = 1.5 * t1 * (2.0 + bmax) / sqrt(r.AC2);
+#pragma unroll
+	for (int k = 0; k < K; k++) bmax += fabs(c[k]) * md.Xabs[k];
+	const double t1 = fabs(S) * sqrt(AC2) / (sqrt(md.r) * var2);
+	const double x = 1.5 * t1 * (2.0 + bmax) / sqrt(AC2);
 	// Few carriers: one workgroup builds the variant's list once (a pass per sample segment would be
 	// all overhead) and runs the series or, where that is hopeless, the exact sweeps on it.
-	if (r.nnz <= SPA5_NNZ) return (x <= SPA5_EXACT_X) ? 2 : 3;
+	if (nnz <= SPA5_NNZ) return (x <= SPA5_EXACT_X) ? 2 : 3;
 	return (x <= SPA4_TIER_X) ? 0 : 1;
 }
 
-// Record of a flagged variant into recs[]: tier A from slot 0 upwards (counters[0]), tier B from slot
-// btop - 1 downwards (counters[7]), the variants of the per-variant kernels from slot btop upwards
-// (counters[5]; their indices also onto the list of their kernel: fb_series / counters[3] or
-// fb_exact / counters[4]).  btop = 0: one range only.
+// Record of a flagged variant into recs[] (written field by field: no copy of the record on the stack):
+// tier A from slot 0 upwards (counters[0]), tier B from slot btop - 1 downwards (counters[7]), the
+// variants of the per-variant kernels from slot btop upwards (counters[5]; their indices also onto the list
+// of their kernel: fb_series / counters[3] or fb_exact / counters[4]).  btop = 0: one range only.
+template <int K>
 __device__ __forceinline__ void spa_push(const DevModel &md, SpaRec *recs, int *counters, int btop, int *fb_series,
-	int *fb_exact, const SpaRec &r)
+	int *fb_exact, int j, int minus, double AC2, int nnz, const double (&lut)[4], double pn, double S, double var2,
+	const double (&c)[KMAX])
 {
-	const int tier = btop > 0 ? spa_tier(md, r) : 0;
+	const int tier = btop > 0 ? spa_tier<K>(md, nnz, S, var2, AC2, c) : 0;
 	int slot;
 	if (tier >= 2) {
 		slot = btop + atomicAdd(&counters[5], 1);
@@ -310,7 +314,14 @@ __device__ __forceinline__ void spa_push(const DevModel &md, SpaRec *recs, int *
 	} else {
 		slot = tier ? btop - 1 - atomicAdd(&counters[7], 1) : atomicAdd(&counters[0], 1);
 	}
-	recs[slot] = r;
+	SpaRec *r = recs + slot;
+	r->j = j; r->minus = minus; r->nnz = nnz; r->has_gmu = 0;
+#pragma unroll
+	for (int k = 0; k < 4; k++) r->lut[k] = lut[k];
+	r->AC2 = AC2; r->p_noadj = pn; r->S = S; r->var2 = var2; r->sum_gmu = 0;
+	r->tscale = spa_tscale(S, var2, AC2, md.r);
+#pragma unroll
+	for (int k = 0; k < KMAX; k++) r->c[k] = c[k];
 }
 
 // Score epilogue: from the P reduced sums to the output row; returns 1 when the

@@ -374,15 +374,8 @@ score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf
 	double cbuf[KMAX], pn, Ssc, v2sc;
 	valid[j] = 1;
 	if (score_epilogue<(P - 2) / 2>(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
-		SpaRec rr;
-		rr.j = j; rr.minus = h.minus; rr.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
-		rr.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); rr.has_gmu = 0; rr.sum_gmu = 0;   // m1: SPA stage, carrier sums
-		rr.p_noadj = pn; rr.S = Ssc; rr.var2 = v2sc; rr.tscale = spa_tscale(Ssc, v2sc, rr.AC2, md.r);
-		for (int k = 0; k < 4; k++) rr.lut[k] = h.lut[k];
-		
-#pragma unroll
-		for (int k = 0; k < KMAX; k++) rr.c[k] = cbuf[k];
-		spa_push(md, recs, counters, btop, fb_series, fb_exact, rr);
+		spa_push<K>(md, recs, counters, btop, fb_series, fb_exact, j, h.minus, h.minus ? (2 * h.Num - h.AC) : h.AC,
+			h.minus ? (N - n2) : (n1 + n2 + n3), h.lut, pn, Ssc, v2sc, cbuf);     // m1: SPA stage, carrier sums
 	}
 	atomicAdd(&counters[1], 1);
 }

@@ -261,7 +261,7 @@ static int alloc_workspace(sgx_handle *h)
 	h->scratch_stride = 2 * (((size_t)N + 63) & ~(size_t)63);
 	HIPCHK(hipMalloc((void **)&h->scratch, h->scratch_stride * sizeof(double) * h->spa_grid));
 	if (!h->md.quant) {
-		h->nwg5 = h->n_cu * 2;
+		h->nwg5 = h->n_cu;              // one workgroup per CU is resident (row staging in LDS, 256 registers)
 		HIPCHK(hipMalloc((void **)&h->scr5, (size_t)h->nwg5 * spa5_wg_bytes(N)));
 		HIPCHK(hipMalloc((void **)&h->cur5, 2 * sizeof(int)));
 	}
