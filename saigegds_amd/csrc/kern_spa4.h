@@ -471,6 +471,11 @@ __device__ __forceinline__ bool spa4_root(const Spa4Series<NC> &S, double xmax, 
 	return true;
 }
 
+template <int K, int NC>
+__device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int tier, int btop, int v0, int vcap, int v, int lane,
+	SpaRec *__restrict__ recs, int *__restrict__ counters, const double *__restrict__ segpart,
+	int *__restrict__ fb_dense, int *__restrict__ fb_spa2, double *__restrict__ out8, int force_dense, int force_exact);
+
 // one wave per flagged variant of the tier's round [v0, v0 + vcap).  A tier-A variant whose series
 // is too short is handed to tier B (a copy of its record at the end of that range); from tier B it goes
 // to the exact kernels.
@@ -480,12 +485,21 @@ spa4_solve(DevModel md, int nseg, int tier, int btop, int v0, int vcap, SpaRec *
 	const double *__restrict__ segpart, int *__restrict__ fb_dense, int *__restrict__ fb_spa2,
 	double *__restrict__ out8, int force_dense, int force_exact)
 {
-	constexpr int NS = NC + 5;
 	// one wave per variant: the lanes share the segments' partial sums (fixed tree), then all of
 	// them run the scalar part on identical values and lane 0 writes
 	const int lane = threadIdx.x & (WAVE - 1);
-	const int v = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE;
-	if (v >= min(counters[tier ? 7 : 0] - v0, vcap)) return;
+	const int nflag = min(counters[tier ? 7 : 0] - v0, vcap);
+	for (int v = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE; v < nflag; v += gridDim.x * blockDim.x / WAVE)
+		spa4_solve_one<K, NC>(md, nseg, tier, btop, v0, vcap, v, lane, recs, counters, segpart, fb_dense, fb_spa2, out8,
+			force_dense, force_exact);
+}
+
+template <int K, int NC>
+__device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int tier, int btop, int v0, int vcap, int v, int lane,
+	SpaRec *__restrict__ recs, int *__restrict__ counters, const double *__restrict__ segpart,
+	int *__restrict__ fb_dense, int *__restrict__ fb_spa2, double *__restrict__ out8, int force_dense, int force_exact)
+{
+	constexpr int NS = NC + 5;
 	const int ri = spa4_rec(tier, btop, v0 + v);
 	const SpaRec r = recs[ri];
 	double a[NS];

@@ -673,7 +673,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			}                                                                                \
 			const int nround = (int)((M + h->vcap4 - 1) / h->vcap4);                         \
 			const int btop = (int)(2 * M);                                                   \
-			const dim3 gsolve((unsigned)((h->vcap4 + 3) / 4));       /* one wave per variant */ \
+			const dim3 gsolve((unsigned)std::min((h->vcap4 + 3) / 4, 4 * h->n_cu));   /* a wave per variant, grid-stride */ \
 			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCA, 0, rd);                \
 			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCB, 1, rd);                \
 			/* what the series does not cover: exact exp/log sums, one workgroup per variant; \
