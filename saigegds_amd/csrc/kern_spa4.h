@@ -580,7 +580,6 @@ __device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int
 // the last (kern_spa2.h).  The lists live in the workgroup's slice of global scratch (N entries: any
 // variant fits).
 
-#define SPA5_BLOCK 512
 #define SPA5_BIG 2048            /* lists longer than this are started first (they set the kernel's tail) */
 
 // K1, K2 (SPATest.cpp:64,79-80) and Korg (:49) terms of one carrier at t; the Korg term switched at run time (workgroup-uniform)
@@ -601,13 +600,14 @@ __host__ __device__ inline size_t spa5_wg_bytes(int N) { return (((size_t)N + 63
 
 // this thread's share of the cumulant sums over a variant's list (a call: the polynomial constants stay
 // out of the caller's registers)
+template <int BLOCK>
 __device__ __noinline__ void spa5_cum_sweep(const double2 *__restrict__ glist, int nnz, double ts, double *kp_out)
 {
 	constexpr int NC = SPA4_NCB;
 	double kp[NC - 1];
 #pragma unroll
 	for (int a = 0; a < NC - 1; a++) kp[a] = 0;
-	for (int k = threadIdx.x; k < nnz; k += SPA5_BLOCK) {
+	for (int k = threadIdx.x; k < nnz; k += BLOCK) {
 		const double2 gm = glist[k];
 		const double mui = gm.y;
 		spa4_cum_terms<NC>(gm.x * ts, mui * (1 - mui), 1 - 2 * mui, kp);
@@ -648,27 +648,28 @@ __device__ __noinline__ int spa5_series_solve(const double *arg, const SpaRec *_
 // The series on a variant's (adj, mu) list (spa5_kernel): one sweep for the cumulant sums, then thread 0
 // runs both root searches and the tail on them.  Returns (to every thread) whether the row was written;
 // false = some evaluation point lies outside what sixteen cumulants cover: the caller goes on with the
-// exact sweeps.  sh: (NC - 1) * (SPA5_BLOCK / 64) + NC + 16 doubles of shared memory.
+// exact sweeps.  sh: (NC - 1) * (BLOCK / 64) + NC + 16 doubles of shared memory.
+template <int BLOCK>
 __device__ __forceinline__ bool spa5_series(const double2 *__restrict__ glist, int nnz, double ts, double xmax,
 	double k1, double k2, double qtilde, double qinv, double NAmu, double NAsigma, double pn_in,
 	double Tstat, double var1, const SpaRec *__restrict__ rec, double *__restrict__ out8, double *sh, int *sh_flag)
 {
 	constexpr int NC = SPA4_NCB;
 	double kp[NC - 1];                 // kappa'_3..NC, and max |adj| in the last slot
-	spa5_cum_sweep(glist, nnz, ts, kp);
+	spa5_cum_sweep<BLOCK>(glist, nnz, ts, kp);
 	// sums of the cumulants; the maximum through the same tree would be wrong, so it goes apart
 	double gmax = kp[NC - 2];
 	kp[NC - 2] = 0;
-	block_sum<NC - 1, SPA5_BLOCK>(kp, sh);
+	block_sum<NC - 1, BLOCK>(kp, sh);
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o, WAVE));
 	if ((threadIdx.x & (WAVE - 1)) == 0) sh[threadIdx.x / WAVE] = gmax;
 	__syncthreads();
 	if (threadIdx.x == 0) {
-		for (int w = 0; w < SPA5_BLOCK / WAVE; w++) gmax = fmax(gmax, sh[w]);
+		for (int w = 0; w < BLOCK / WAVE; w++) gmax = fmax(gmax, sh[w]);
 		// the scalar part as a call: its registers (two root searches on sixteen cumulants) stay out of
 		// the workgroup's budget
-		double *arg = sh + SPA5_BLOCK / WAVE;
+		double *arg = sh + BLOCK / WAVE;
 #pragma unroll
 		for (int a = 0; a < NC - 2; a++) arg[a] = kp[a];
 		arg[NC - 2] = k1; arg[NC - 1] = k2; arg[NC] = ts; arg[NC + 1] = gmax; arg[NC + 2] = xmax;
@@ -684,14 +685,16 @@ __device__ __forceinline__ bool spa5_series(const double2 *__restrict__ glist, i
 
 // MODE 0: the series on the list; variants it does not cover are appended to `todo_next` (counters[4]).
 // MODE 1: the exact sweeps (over that list).
-template <int K, int INPUT, int MODE>
-__global__ void __launch_bounds__(SPA5_BLOCK)
+// BLOCK: 512 threads per variant, or 128 where the packed row is short enough for four workgroups per CU
+// (small N: the kernel is bound by the number of variants in flight, not by the work in one).
+template <int K, int INPUT, int MODE, int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
 spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec *__restrict__ recs,
 	int *__restrict__ counters, const int *__restrict__ todo, int *__restrict__ todo_next, int *__restrict__ cursor,
 	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8, int force_dense, int force_exact,
 	size_t lds_row_bytes)
 {
-	constexpr int KP = (K + 2) & ~1, NW = SPA5_BLOCK / WAVE;
+	constexpr int KP = (K + 2) & ~1, NW = BLOCK / WAVE;
 	extern __shared__ __attribute__((aligned(16))) uint8_t fill_smem[];
 	uint4 *rows_lds = reinterpret_cast<uint4 *>(fill_smem);
 	__shared__ double sh[SPA4_NCB * NW + SPA4_NCB + 16];
@@ -742,12 +745,12 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 		const bool staged = INPUT == IN_2BIT && lds_row_bytes >= (size_t)nvec * 16;
 		if (staged) {
 			constexpr int UN = 8;
-			for (int p0 = tid; p0 < nvec; p0 += UN * SPA5_BLOCK) {
+			for (int p0 = tid; p0 < nvec; p0 += UN * BLOCK) {
 				uint4 t[UN];
 #pragma unroll
-				for (int j = 0; j < UN; j++) { const int p = p0 + j * SPA5_BLOCK; t[j] = p < nvec ? row[p] : make_uint4(0u, 0u, 0u, 0u); }
+				for (int j = 0; j < UN; j++) { const int p = p0 + j * BLOCK; t[j] = p < nvec ? row[p] : make_uint4(0u, 0u, 0u, 0u); }
 #pragma unroll
-				for (int j = 0; j < UN; j++) { const int p = p0 + j * SPA5_BLOCK; if (p < nvec) rows_lds[p] = t[j]; }
+				for (int j = 0; j < UN; j++) { const int p = p0 + j * BLOCK; if (p < nvec) rows_lds[p] = t[j]; }
 			}
 			__syncthreads();
 		}
@@ -823,11 +826,11 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 #pragma unroll
 		for (int a = 0; a < K; a++) c[a] = r.c[a];
 		double a6[6] = {0, 0, 0, 0, 0, 0};
-		for (int k0 = tid; k0 < ((force_exact & 128) ? 0 : nnz); k0 += 2 * SPA5_BLOCK) {
+		for (int k0 = tid; k0 < ((force_exact & 128) ? 0 : nnz); k0 += 2 * BLOCK) {
 			uint32_t e[2];
 			double xv[2][KP];
 #pragma unroll
-			for (int j = 0; j < 2; j++) e[j] = (k0 + j * SPA5_BLOCK < nnz) ? ilist[k0 + j * SPA5_BLOCK] : 0u;
+			for (int j = 0; j < 2; j++) e[j] = (k0 + j * BLOCK < nnz) ? ilist[k0 + j * BLOCK] : 0u;
 #pragma unroll
 			for (int j = 0; j < 2; j++) {
 				const double *x = md.XM + (size_t)(e[j] & 0x3FFFFFFFu) * KP;
@@ -839,7 +842,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			}
 #pragma unroll
 			for (int j = 0; j < 2; j++) {
-				const int k = k0 + j * SPA5_BLOCK;
+				const int k = k0 + j * BLOCK;
 				if (k >= nnz) continue;
 				const uint32_t code = e[j] >> 30;
 				const double G = INPUT == IN_2BIT ? ((code & 2u) ? ((code & 1u) ? lut3 : lut2) : ((code & 1u) ? lut1 : lut0))
@@ -857,7 +860,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 				a6[5] = fma(adj * adj, mui * (1 - mui), a6[5]);
 			}
 		}
-		block_sum<6, SPA5_BLOCK>(a6, sh);        // its barriers also publish the list
+		block_sum<6, BLOCK>(a6, sh);        // its barriers also publish the list
 		// ---- scalars of saige_main.cpp:369-381, then Saddle_Prob_Fast
 		double xmu_c = 0, xsum_c = 0;
 #pragma unroll
@@ -883,7 +886,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			const double NAmu = m1 - a6[4], NAsigma = var2 - a6[5];
 			if (MODE == 0) {
 				// the series: one sweep over the list instead of one per Newton step
-				if ((force_exact & 1) || !spa5_series(glist, nnz, r.tscale, md.spa_xmax, a6[4], a6[5], qtilde, qinv, NAmu, NAsigma,
+				if ((force_exact & 1) || !spa5_series<BLOCK>(glist, nnz, r.tscale, md.spa_xmax, a6[4], a6[5], qtilde, qinv, NAmu, NAsigma,
 						pn_in, Tstat, var1, &sh_rec, out8, sh, &sh_flag)) {
 					if (tid == 0) todo_next[atomicAdd(&counters[4], 1)] = v;     // on to the exact exp/log sweeps
 				}
@@ -899,13 +902,13 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 #pragma unroll
 				for (int a = 0; a < 6; a++) sv[a] = 0;
 				double2 gn = tid < nnz ? glist[tid] : make_double2(0.0, 0.5);            // g = 0 adds exactly 0
-				for (int k0 = tid; k0 < nnz; k0 += SPA5_BLOCK) {
+				for (int k0 = tid; k0 < nnz; k0 += BLOCK) {
 					const double2 gm = gn;
-					if (k0 + SPA5_BLOCK < nnz) gn = glist[k0 + SPA5_BLOCK];              // one step ahead
+					if (k0 + BLOCK < nnz) gn = glist[k0 + BLOCK];              // one step ahead
 					if (a1) cgf_terms_rt(gm.x, gm.y, t1, k1w, sv[0], sv[1], sv[2]);
 					if (a2) cgf_terms_rt(gm.x, gm.y, t2, k2w, sv[3], sv[4], sv[5]);
 				}
-				block_sum<6, SPA5_BLOCK>(sv, sh);
+				block_sum<6, BLOCK>(sv, sh);
 			};
 			while ((s1.active || s2.active) && !(force_exact & 64)) {
 				const bool a1 = s1.active, a2 = s2.active, k1w = s1.want_k, k2w = s2.want_k;

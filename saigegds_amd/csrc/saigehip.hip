@@ -261,7 +261,9 @@ static int alloc_workspace(sgx_handle *h)
 	h->scratch_stride = 2 * (((size_t)N + 63) & ~(size_t)63);
 	HIPCHK(hipMalloc((void **)&h->scratch, h->scratch_stride * sizeof(double) * h->spa_grid));
 	if (!h->md.quant) {
-		h->nwg5 = h->n_cu;              // one workgroup per CU is resident (row staging in LDS, 256 registers)
+		// workgroups of the per-variant kernels, each with its scratch lists: 4 per CU where a packed row is
+		// short (128-thread workgroups, see the launch), else one
+		h->nwg5 = (size_t)((N + 63) / 64) * 16 <= 32 * 1024 ? h->n_cu * 4 : h->n_cu;
 		HIPCHK(hipMalloc((void **)&h->scr5, (size_t)h->nwg5 * spa5_wg_bytes(N)));
 		HIPCHK(hipMalloc((void **)&h->cur5, 2 * sizeof(int)));
 	}
@@ -678,22 +680,33 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCB, 1, rd);                \
 			/* what the series does not cover: exact exp/log sums, one workgroup per variant; \
 			   then the exact dense g_pos / g_neg pass */                                    \
-			/* a packed row in LDS when it fits beside the kernel's static shared memory */  \
+			/* a packed row in LDS when it fits; short rows: 128 threads per variant, 4 workgroups per CU */ \
 			const size_t rowb5 = (size_t)((md.N + 63) / 64) * 16;                            \
 			const size_t l5 = (INPUT == IN_2BIT && rowb5 <= 120 * 1024) ? rowb5 : 0;         \
+			const bool small5 = INPUT == IN_2BIT && rowb5 <= 32 * 1024;                      \
 			if (l5 > 48 * 1024 && !h->spa5_attr_set[INPUT]) {                                \
-				HIPCHK(hipFuncSetAttribute((const void *)spa5_kernel<KK, INPUT, 0>,          \
+				HIPCHK(hipFuncSetAttribute((const void *)spa5_kernel<KK, INPUT, 0, 512>,     \
 					hipFuncAttributeMaxDynamicSharedMemorySize, (int)l5));                   \
-				HIPCHK(hipFuncSetAttribute((const void *)spa5_kernel<KK, INPUT, 1>,          \
+				HIPCHK(hipFuncSetAttribute((const void *)spa5_kernel<KK, INPUT, 1, 512>,     \
 					hipFuncAttributeMaxDynamicSharedMemorySize, (int)l5));                   \
 				h->spa5_attr_set[INPUT] = true;                                              \
 			}                                                                                \
-			hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 0>), dim3((unsigned)h->nwg5), dim3(SPA5_BLOCK), \
-				l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
-				h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, (h->force_exact ? 1 : 0) | (h->spa_abl & ~1), l5); \
-			hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 1>), dim3((unsigned)h->nwg5), dim3(SPA5_BLOCK), \
-				l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
-				h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, (h->force_exact ? 1 : 0) | (h->spa_abl & ~1), l5); \
+			const int fx5 = (h->force_exact ? 1 : 0) | (h->spa_abl & ~1);                    \
+			if (small5) {                                                                    \
+				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 0, 128>), dim3((unsigned)h->nwg5), dim3(128), \
+					l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 1, 128>), dim3((unsigned)h->nwg5), dim3(128), \
+					l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+			} else {                                                                         \
+				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 0, 512>), dim3((unsigned)h->n_cu), dim3(512), \
+					l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 1, 512>), dim3((unsigned)h->n_cu), dim3(512), \
+					l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+			}                                                                                \
 			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
 				row_bytes, md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
 				h->scratch_stride, out8);                                                    \
