@@ -21,6 +21,22 @@ thr_d = torch.from_numpy(thr.view(np.int32)).to(dev)
 torch.cuda.synchronize()
 sc.synth_2bit_dev(packed.data_ptr(), bpv, block, 0, seed, thr_d.data_ptr())
 sc.sync()
+# carriers of the flagged variants (codes other than the major-allele homozygote, missing included)
+sc.scan_2bit_dev(packed.data_ptr(), bpv, block, out.data_ptr(), valid.data_ptr())
+sc.sync()
+o = out.cpu().numpy(); va = valid.cpu().numpy().astype(bool)
+fl = np.where(va & (o[:, 6] <= 0.05))[0]
+lutc = torch.tensor([bin(b & 0x55 | (b >> 1) & 0x55).count("1") for b in range(256)], dtype=torch.int32, device=dev)
+nnz = []
+for j0 in range(0, fl.size, 256):
+    rows = packed[torch.from_numpy(fl[j0:j0 + 256]).to(dev)]
+    flip = torch.from_numpy((o[fl[j0:j0 + 256], 0] > 0.5)).to(dev)
+    rows = torch.where(flip[:, None], rows ^ 0xAA, rows)
+    nnz.append(lutc[rows.long()].sum(1).cpu().numpy())
+nnz = np.concatenate(nnz)
+big = nnz > 16384
+print(f"flagged {fl.size}: {big.sum()} with more than 16384 carriers ({nnz[big].sum():.3e} carriers), "
+      f"{(~big).sum()} below ({nnz[~big].sum():.3e})", flush=True)
 for abl in [int(a) for a in (sys.argv[1:] or ["0", "1", "2", "3", "4", "12"])]:
     sc.set_option("spa_abl", abl)
     for i in range(2):
