@@ -255,13 +255,16 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 				gmax = fmax(gmax, fabs(adj));
 				if (!(abl & 1)) spa4_cum_terms<NC>(adj * ts, u, 1 - 2 * mui, &acc[6]);
 			};
-			// A lane owns 64 samples, so the lanes' carrier counts differ (binomial): walking them in
-			// lock step to the largest count would leave ~40 % of the lane-steps empty.  Instead: T =
+			// A lane owns 64 samples, so the lanes' carrier counts differ (binomial): walking them in lock
+			// step to the largest count would leave ~40 % of the lane-steps empty.  Instead: T =
 			// ceil(mean count) lock-step rounds, then whatever the busier lanes have left goes through
-			// the wave's LDS queue and is shared out evenly, 64 carriers a round.
-			const int T = (wave_sum_i(__popc(lo) + __popc(hi)) + WAVE - 1) / WAVE;
+			// the wave's LDS queue and is shared out evenly, 64 carriers a round.  (abl & 256: everything
+			// the queue holds goes through it -- measured, no faster: filling the queue costs what the
+			// idle lane-steps do.)
+			const int ctot = wave_sum_i(__popc(lo) + __popc(hi));
+			const int T = (abl & 256) ? max(0, (ctot - spa4_qcap(K) + WAVE - 1) / WAVE) : (ctot + WAVE - 1) / WAVE;
 			Car ca, cb;
-			fetch(ca);
+			if (T > 0) fetch(ca);
 			for (int it = 0; it < T; it += 2) {
 				if (it + 1 < T) fetch(cb); else cb.ok = false;
 				if (ca.ok) work(ca);
@@ -607,8 +610,10 @@ __device__ __noinline__ void spa5_cum_sweep(const double2 *__restrict__ glist, i
 	double kp[NC - 1];
 #pragma unroll
 	for (int a = 0; a < NC - 1; a++) kp[a] = 0;
+	double2 gn = (int)threadIdx.x < nnz ? glist[threadIdx.x] : make_double2(0.0, 0.5);
 	for (int k = threadIdx.x; k < nnz; k += BLOCK) {
-		const double2 gm = glist[k];
+		const double2 gm = gn;
+		if (k + BLOCK < nnz) gn = glist[k + BLOCK];                  // one step ahead
 		const double mui = gm.y;
 		spa4_cum_terms<NC>(gm.x * ts, mui * (1 - mui), 1 - 2 * mui, kp);
 		kp[NC - 2] = fmax(kp[NC - 2], fabs(gm.x));
@@ -648,35 +653,55 @@ __device__ __noinline__ int spa5_series_solve(const double *arg, const SpaRec *_
 // The series on a variant's (adj, mu) list (spa5_kernel): one sweep for the cumulant sums, then thread 0
 // runs both root searches and the tail on them.  Returns (to every thread) whether the row was written;
 // false = some evaluation point lies outside what sixteen cumulants cover: the caller goes on with the
-// exact sweeps.  sh: (NC - 1) * (BLOCK / 64) + NC + 16 doubles of shared memory.
+// exact sweeps.  sh: NC + 16 + (NC - 1) * (BLOCK / 64) doubles of shared memory.
 template <int BLOCK>
 __device__ __forceinline__ bool spa5_series(const double2 *__restrict__ glist, int nnz, double ts, double xmax,
 	double k1, double k2, double qtilde, double qinv, double NAmu, double NAsigma, double pn_in,
-	double Tstat, double var1, const SpaRec *__restrict__ rec, double *__restrict__ out8, double *sh, int *sh_flag)
+	double Tstat, double var1, const SpaRec *__restrict__ rec, double *__restrict__ out8, double *sh, int *sh_flag, int *prof = nullptr)
 {
 	constexpr int NC = SPA4_NCB;
 	double kp[NC - 1];                 // kappa'_3..NC, and max |adj| in the last slot
+#ifdef SPA5_PROF
+	long long tp_ = wall_clock64();
+#define SPA5_TS(ph) do { if (threadIdx.x == 0) { const long long now_ = wall_clock64(); atomicAdd(&prof[ph], (int)(now_ - tp_)); tp_ = now_; } } while (0)
+#else
+#define SPA5_TS(ph) do { } while (0)
+#endif
 	spa5_cum_sweep<BLOCK>(glist, nnz, ts, kp);
-	// sums of the cumulants; the maximum through the same tree would be wrong, so it goes apart
+	SPA5_TS(0);
+	// Only thread 0 needs the totals: a reduce-scatter inside each wave (wave_reduce_scatter: ~NC shuffles
+	// instead of 6 NC), the waves' partial sums through LDS, NC - 2 threads add them up
+	constexpr int NWV = BLOCK / WAVE;
 	double gmax = kp[NC - 2];
-	kp[NC - 2] = 0;
-	block_sum<NC - 1, BLOCK>(kp, sh);
+	const int lane = threadIdx.x & (WAVE - 1), wv = threadIdx.x / WAVE;
+	double kr[NC - 2];
+#pragma unroll
+	for (int a = 0; a < NC - 2; a++) kr[a] = kp[a];
+	const int idx = wave_reduce_scatter(kr, lane);
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o, WAVE));
-	if ((threadIdx.x & (WAVE - 1)) == 0) sh[threadIdx.x / WAVE] = gmax;
+	double *part = sh + NC + 16;                                  // [NC - 2][NWV] partial sums, [NWV] maxima
+	if (!(lane & 3) && idx < NC - 2) part[idx * NWV + wv] = kr[0];
+	if (lane == 1) part[(NC - 2) * NWV + wv] = gmax;
 	__syncthreads();
+	double *arg = sh;
+	if (threadIdx.x < NC - 2) {
+		double t = 0;
+		for (int w = 0; w < NWV; w++) t += part[threadIdx.x * NWV + w];
+		arg[threadIdx.x] = t;
+	}
+	__syncthreads();
+	SPA5_TS(1);
 	if (threadIdx.x == 0) {
-		for (int w = 0; w < BLOCK / WAVE; w++) gmax = fmax(gmax, sh[w]);
+		for (int w = 0; w < NWV; w++) gmax = fmax(gmax, part[(NC - 2) * NWV + w]);
 		// the scalar part as a call: its registers (two root searches on sixteen cumulants) stay out of
 		// the workgroup's budget
-		double *arg = sh + BLOCK / WAVE;
-#pragma unroll
-		for (int a = 0; a < NC - 2; a++) arg[a] = kp[a];
 		arg[NC - 2] = k1; arg[NC - 1] = k2; arg[NC] = ts; arg[NC + 1] = gmax; arg[NC + 2] = xmax;
 		arg[NC + 3] = qtilde; arg[NC + 4] = qinv; arg[NC + 5] = NAmu; arg[NC + 6] = NAsigma;
 		arg[NC + 7] = pn_in; arg[NC + 8] = Tstat; arg[NC + 9] = var1;
 		*sh_flag = spa5_series_solve(arg, rec, out8);
 	}
+	SPA5_TS(2);
 	__syncthreads();
 	const bool done = *sh_flag != 0;
 	__syncthreads();                   // sh and the flag are free again
@@ -687,6 +712,11 @@ __device__ __forceinline__ bool spa5_series(const double2 *__restrict__ glist, i
 // MODE 1: the exact sweeps (over that list).
 // BLOCK: 512 threads per variant, or 128 where the packed row is short enough for four workgroups per CU
 // (small N: the kernel is bound by the number of variants in flight, not by the work in one).
+#ifdef SPA5_PROF   /* phase times of spa5_kernel in 10-ns ticks -> counters[8 + 8 MODE + phase] (diagnostic build only) */
+#define SPA5_T(ph) do { if (tid == 0) { const long long now_ = wall_clock64(); atomicAdd(&counters[8 + 8 * MODE + (ph)], (int)(now_ - tprev_)); tprev_ = now_; } } while (0)
+#else
+#define SPA5_T(ph) do { } while (0)
+#endif
 template <int K, int INPUT, int MODE, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec *__restrict__ recs,
@@ -729,6 +759,9 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 		__syncthreads();
 		const int vi = sh_vi;
 		if (vi >= 2 * ntodo) break;
+#ifdef SPA5_PROF
+		long long tprev_ = wall_clock64();
+#endif
 		const bool big_round = vi < ntodo;
 		const int v = sh_v;
 		const SpaRec &r = sh_rec;
@@ -754,6 +787,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			}
 			__syncthreads();
 		}
+		SPA5_T(0);
 		auto masks = [&](int p, uint32_t (&ww)[4], uint32_t (&z)[4]) -> int {
 			int cnt = 0;
 			if (INPUT == IN_2BIT) {
@@ -784,6 +818,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 		int o_w = 0, nnz = 0;
 #pragma unroll
 		for (int w = 0; w < NW; w++) { if (w < wid) o_w += shi[w]; nnz += shi[w]; }
+		SPA5_T(1);
 		for (int it = 0; it < per; it += WAVE) {
 			uint32_t ww[4], z[4];
 			const int p = wid * per + it + lane;
@@ -820,19 +855,23 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			}
 		}
 		__syncthreads();                         // publishes the index list to the workgroup
+		SPA5_T(2);
 		// ---- (adj, mu) list + carrier sums (kern_spa2.h)
 		const double inv = 1 / sqrt(r.AC2);
 		double c[K];
 #pragma unroll
 		for (int a = 0; a < K; a++) c[a] = r.c[a];
 		double a6[6] = {0, 0, 0, 0, 0, 0};
-		for (int k0 = tid; k0 < ((force_exact & 128) ? 0 : nnz); k0 += 2 * BLOCK) {
-			uint32_t e[2];
-			double xv[2][KP];
+		// (UNG independent index reads, then UNG independent row gathers per thread and step: the loop is
+		// bound by the two global latencies in a row, not by its arithmetic)
+		constexpr int UNG = K <= 4 ? 4 : 2;
+		for (int k0 = tid; k0 < ((force_exact & 128) ? 0 : nnz); k0 += UNG * BLOCK) {
+			uint32_t e[UNG];
+			double xv[UNG][KP];
 #pragma unroll
-			for (int j = 0; j < 2; j++) e[j] = (k0 + j * BLOCK < nnz) ? ilist[k0 + j * BLOCK] : 0u;
+			for (int j = 0; j < UNG; j++) e[j] = (k0 + j * BLOCK < nnz) ? ilist[k0 + j * BLOCK] : 0u;
 #pragma unroll
-			for (int j = 0; j < 2; j++) {
+			for (int j = 0; j < UNG; j++) {
 				const double *x = md.XM + (size_t)(e[j] & 0x3FFFFFFFu) * KP;
 #pragma unroll
 				for (int a = 0; a < KP; a += 2) {
@@ -841,7 +880,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 				}
 			}
 #pragma unroll
-			for (int j = 0; j < 2; j++) {
+			for (int j = 0; j < UNG; j++) {
 				const int k = k0 + j * BLOCK;
 				if (k >= nnz) continue;
 				const uint32_t code = e[j] >> 30;
@@ -861,6 +900,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			}
 		}
 		block_sum<6, BLOCK>(a6, sh);        // its barriers also publish the list
+		SPA5_T(3);
 		// ---- scalars of saige_main.cpp:369-381, then Saddle_Prob_Fast
 		double xmu_c = 0, xsum_c = 0;
 #pragma unroll
@@ -887,9 +927,10 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			if (MODE == 0) {
 				// the series: one sweep over the list instead of one per Newton step
 				if ((force_exact & 1) || !spa5_series<BLOCK>(glist, nnz, r.tscale, md.spa_xmax, a6[4], a6[5], qtilde, qinv, NAmu, NAsigma,
-						pn_in, Tstat, var1, &sh_rec, out8, sh, &sh_flag)) {
+						pn_in, Tstat, var1, &sh_rec, out8, sh, &sh_flag, counters + 13)) {
 					if (tid == 0) todo_next[atomicAdd(&counters[4], 1)] = v;     // on to the exact exp/log sweeps
 				}
+				SPA5_T(4);
 				continue;
 			}
 			RootState s1, s2;
@@ -935,5 +976,6 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			}
 		}
 		if (tid == 0) spa_write_row(r, Tstat, var1, pval, converged, out8);
+		SPA5_T(5);
 	}
 }

@@ -250,8 +250,8 @@ static int alloc_workspace(sgx_handle *h)
 {
 	const int N = h->md.N;
 	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-	HIPCHK(hipMalloc((void **)&h->counters, 8 * sizeof(int)));
-	HIPCHK(hipHostMalloc((void **)&h->h_counters, 8 * sizeof(int), hipHostMallocDefault));
+	HIPCHK(hipMalloc((void **)&h->counters, 24 * sizeof(int)));
+	HIPCHK(hipHostMalloc((void **)&h->h_counters, 24 * sizeof(int), hipHostMallocDefault));
 	for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&h->ev[i]));
 	// SPA scratch: one (adj, mu) list of N entries per resident workgroup
 	hipDeviceProp_t prop;
@@ -553,7 +553,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	const DevModel &md = h->md;
 	constexpr int SB = 256, PB = 512;
 	hipStream_t st = h->stream;
-	HIPCHK(hipMemsetAsync(h->counters, 0, 8 * sizeof(int), st));
+	HIPCHK(hipMemsetAsync(h->counters, 0, 24 * sizeof(int), st));
 	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 2 * sizeof(int), st));
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	const bool use_mf = (INPUT == IN_2BIT) && h->mf_ok && !h->force_v1;
@@ -720,7 +720,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		h->stats.spa_launches = (h->force_v1 && INPUT != IN_2BIT) ? 1u : (uint32_t)(4 * ((M + h->vcap4 - 1) / h->vcap4) + 3);
 	}
 	HIPCHK(hipEventRecord(h->ev[2], st));
-	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 8 * sizeof(int), hipMemcpyDeviceToHost, st));
+	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 24 * sizeof(int), hipMemcpyDeviceToHost, st));
 	h->stats.n_variants = M;
 	h->stats_pending = true;
 	return SGX_OK;
@@ -772,6 +772,11 @@ static int sync_lane(sgx_handle *h)
 		h->stats.n_valid = (uint64_t)h->h_counters[1];
 		h->stats.n_spa_dense = (uint64_t)h->h_counters[2];
 		h->stats.n_spa_slow = (uint64_t)h->h_counters[4];
+#ifdef SPA5_PROF
+		fprintf(stderr, "spa5 phases (10 ns ticks summed over variants): series kernel %d variants: stage %d count %d index %d gather %d series %d (sweep %d sum %d solve %d) | exact kernel %d variants: stage %d count %d index %d gather %d - sweeps %d\n",
+			h->h_counters[3], h->h_counters[8], h->h_counters[9], h->h_counters[10], h->h_counters[11], h->h_counters[12], h->h_counters[13], h->h_counters[14], h->h_counters[15],
+			h->h_counters[4], h->h_counters[16], h->h_counters[17], h->h_counters[18], h->h_counters[19], h->h_counters[21]);
+#endif
 		float a = 0, b = 0, c = 0;
 		(void)hipEventElapsedTime(&a, h->ev[0], h->ev[1]);
 		(void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
