@@ -38,8 +38,10 @@
 //                 the cutoff exit (SPATest.cpp:319-321), both root searches (root_feed / root_step of
 //                 kern_spa2.h, fed from the series), tail probabilities, SE, the output row
 
+// waves of spa4_moments' one workgroup per CU: 12 = three per SIMD at 168 registers (measured at C3:
+// 8 waves 1.74 ms for the whole stage, 12 waves 1.57; 16 would need 128 registers and spill)
 #ifndef SPA4_WAVES
-#define SPA4_WAVES 8
+#define SPA4_WAVES 12
 #endif
 #define SPA4_NCA 12              /* cumulants carried for the variants of tier A (small g t: most carriers) */
 #define SPA4_NCB SPA4_NC         /* ... of tier B */
@@ -119,7 +121,7 @@ __device__ __forceinline__ int wave_reduce_scatter(double (&x)[V], int lane)
 #define SPA4_VPER 128            /* flagged variants whose parameters a workgroup holds in LDS at a time */
 
 // entries of a wave's leftover queue
-__host__ __device__ constexpr int spa4_qcap(int K) { return spa_seg(K) / 2 < 1024 ? spa_seg(K) / 2 : 1024; }
+__host__ __device__ constexpr int spa4_qcap(int K) { return spa_seg(K) / 2 < 8192 / SPA4_WAVES ? spa_seg(K) / 2 : (8192 / SPA4_WAVES) & ~63; }
 
 // dynamic LDS of spa4_moments<K>: the segment's table + the parameter slice + a queue per wave
 __host__ __device__ constexpr size_t spa4_lds_bytes(int K)

@@ -643,12 +643,12 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 #define MOMENTS(KK, NCX, TIER, RD)                                                               \
 	do {                                                                                         \
 		if (INPUT == IN_2BIT)                                                                    \
-			hipLaunchKernelGGL((spa4_moments<KK, NCX>), dim3((unsigned)(h->n_cu * (8 / SPA4_WAVES))), \
+			hipLaunchKernelGGL((spa4_moments<KK, NCX>), dim3((unsigned)(h->n_cu * (SPA4_WAVES <= 8 ? 8 / SPA4_WAVES : 1))), \
 				dim3(WAVE * SPA4_WAVES), fl, st, (const uint8_t *)rows, row_bytes, md, h->nseg,  \
 				TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl); \
 		else                                                                                     \
 			hipLaunchKernelGGL((spa4_moments_ds<KK, NCX, (INPUT == IN_2BIT ? IN_U8 : INPUT)>),   \
-				dim3((unsigned)(h->n_cu * (8 / SPA4_WAVES))), dim3(WAVE * SPA4_WAVES), fl, st, rows, row_bytes, md, \
+				dim3((unsigned)(h->n_cu * (SPA4_WAVES <= 8 ? 8 / SPA4_WAVES : 1))), dim3(WAVE * SPA4_WAVES), fl, st, rows, row_bytes, md, \
 				h->nseg, TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4);  \
 		hipLaunchKernelGGL((spa4_solve<KK, NCX>), gsolve, dim3(256), 0, st, md, h->nseg, TIER,   \
 			btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->fallback,         \
