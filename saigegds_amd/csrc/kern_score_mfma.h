@@ -115,8 +115,9 @@ __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 //   1 no missing plane, 2 no bit-1 MFMA, 4 no unpack, 16 no A loads, 32 no B DMA,
 //   64 no arithmetic at all (loads, DMA, LDS reads and barriers only),
 //   1024 s_memtime stamps per tile, 2048 all loads and DMA of a tile issued in one burst at its start
-template <int NBFV, bool HAS_B1, bool WIDE = false, int ABL = 0>
-__global__ void __launch_bounds__(WAVE * MF_WAVES, 8 / MF_WAVES)
+// NAF: A fragments per wave.  4 (2 waves per SIMD at <= 256 registers) or 3 (3 waves per SIMD at <= 168).
+template <int NBFV, bool HAS_B1, bool WIDE = false, int ABL = 0, int NAF = MF_NAF>
+__global__ void __launch_bounds__(WAVE * MF_WAVES, NAF == 4 ? 8 / MF_WAVES : 12 / MF_WAVES)
 score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab tb,
 	int tiles_per_split, int *__restrict__ accbuf, int acc_stride)
 {
@@ -126,7 +127,7 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 	constexpr int NDMA = (TILE_BYTES / 1024 + MF_WAVES - 1) / MF_WAVES;   // DMA instructions per wave and tile
 	constexpr int AW = WIDE ? 2 : 1;                                      // 16-B pieces of a row held per lane
 	constexpr bool SPREAD = !(ABL & (2048 | 16));   // one VMEM instruction per MFMA group (else: a burst at the tile start)
-	static_assert(AW * MF_NAF + NDMA <= 4 * MF_NAF, "more loads per tile than MFMA groups");
+	static_assert(AW * NAF + NDMA <= 4 * NAF, "more loads per tile than MFMA groups");
 	extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // 2 x TILE_BYTES, nothing else
 	uint8_t *ldsB = smem;
 
@@ -141,13 +142,13 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 		const unsigned VT = gridDim.x, L = blockIdx.y * VT + blockIdx.x, full = gridDim.y & ~7u;
 		if (L < full * VT) { const unsigned q = L >> 3; split = 8 * (q / VT) + (L & 7); vt_idx = q % VT; }
 	}
-	const int vbase = vt_idx * MF_VPB + wid * MF_VPW;
+	const int vbase = vt_idx * (16 * NAF * MF_WAVES) + wid * 16 * NAF;
 	const int t0 = split * tiles_per_split;
 	const int t1 = min(tb.ntile, t0 + tiles_per_split);
 
-	v4i acc[MF_NAF][NBF], accm[MF_NAF][NBFV];
+	v4i acc[NAF][NBF], accm[NAF][NBFV];
 #pragma unroll
-	for (int f = 0; f < MF_NAF; f++) {
+	for (int f = 0; f < NAF; f++) {
 #pragma unroll
 		for (int b = 0; b < NBF; b++) acc[f][b] = (v4i){0, 0, 0, 0};
 #pragma unroll
@@ -158,9 +159,9 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 	// this lane's 16 B of each of its rows in tile t: dwords 16t+4kg .. +3.  Row pointers advance by
 	// 64 B per tile; bpv is a multiple of 64 that covers every tile (sgx_row_stride), rows past M
 	// are clamped (their sums are never stored)
-	const uint8_t *rowp[MF_NAF];
+	const uint8_t *rowp[NAF];
 #pragma unroll
-	for (int f = 0; f < MF_NAF; f++)
+	for (int f = 0; f < NAF; f++)
 		rowp[f] = packed + (size_t)min(vbase + 16 * f + r, M - 1) * bpv + (size_t)t0 * 64 + 16 * kg;
 	auto load_A1 = [&](uint4 &dst, int f, int piece) {
 		if (ABL & 16) { dst = make_uint4(t0 + f, lane, wid, 0x01010101u); return; }
@@ -178,10 +179,10 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 			(__attribute__((address_space(3))) void *)(dst + k * 1024), 16, 0, 0);
 	};
 
-	uint4 acur[MF_NAF][AW], anxt[MF_NAF][AW];
+	uint4 acur[NAF][AW], anxt[NAF][AW];
 	if (t0 < t1) {
 #pragma unroll
-		for (int f = 0; f < MF_NAF; f++)
+		for (int f = 0; f < NAF; f++)
 #pragma unroll
 			for (int p = 0; p < AW; p++) load_A1(acur[f][p], f, p);
 #pragma unroll
@@ -202,17 +203,17 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 		const bool more_A = t + (AW - hh) < t1;          // there is a next row piece set (fetched in the hh = 0 tile)
 		// loads of this tile, spread over its MFMA groups: the A pieces of the next tile (pair), then the next B tile
 		auto vmem_slot = [&](int idx) {
-			if (hh == 0 && idx < AW * MF_NAF) {
+			if (hh == 0 && idx < AW * NAF) {
 				if (more_A) load_A1(anxt[idx / AW][idx % AW], idx / AW, idx % AW);
 			} else {
-				const int i = idx - (hh == 0 ? AW * MF_NAF : 0);
+				const int i = idx - (hh == 0 ? AW * NAF : 0);
 				if (i < NDMA && more_B) dma_B1(t + 1, i);
 			}
 			__builtin_amdgcn_sched_barrier(0);
 		};
 		if (!SPREAD) {
 #pragma unroll
-			for (int idx = 0; idx < 4 * MF_NAF; idx++) vmem_slot(idx);
+			for (int idx = 0; idx < 4 * NAF; idx++) vmem_slot(idx);
 		}
 		if (ABL & 1024) { __builtin_amdgcn_sched_barrier(0); MF_STAMP(sb); __builtin_amdgcn_sched_barrier(0); st_issue += sb - sa; }
 		const uint8_t *bt = ldsB + (size_t)(t & 1) * TILE_BYTES;
@@ -224,10 +225,10 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 			for (int b = 0; b < NBF; b++)
 				bfrag[b] = *reinterpret_cast<const v4i *>(bt + ((size_t)(g * NCOL + b * 16 + r)) * 16);
 #pragma unroll
-			for (int f = 0; f < MF_NAF; f++) {
+			for (int f = 0; f < NAF; f++) {
 				const uint4 aw = acur[f][hh];
 				const uint32_t w = (u == 0) ? aw.x : (u == 1) ? aw.y : (u == 2) ? aw.z : aw.w;
-				if (SPREAD) vmem_slot(u * MF_NAF + f);
+				if (SPREAD) vmem_slot(u * NAF + f);
 				if (ABL & 64) { acc[f][0][0] ^= (int)w ^ bfrag[0][0]; continue; }
 				v4i val, b1;
 				if (ABL & 4) { val = (v4i){(int)w, (int)w, (int)w, (int)w}; b1 = val; }
@@ -252,7 +253,7 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 		if (ABL & 1024) { __builtin_amdgcn_sched_barrier(0); MF_STAMP(st_prev); __builtin_amdgcn_sched_barrier(0); st_comp += st_prev - sb; }
 		if (hh == AW - 1) {
 #pragma unroll
-			for (int f = 0; f < MF_NAF; f++)
+			for (int f = 0; f < NAF; f++)
 #pragma unroll
 				for (int p = 0; p < AW; p++) acur[f][p] = anxt[f][p];
 		}
@@ -273,7 +274,7 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 
 	// ---- results: integer atomics (exact, order-independent)
 #pragma unroll
-	for (int f = 0; f < MF_NAF; f++) {
+	for (int f = 0; f < NAF; f++) {
 #pragma unroll
 		for (int reg = 0; reg < 4; reg++) {
 			const int v = vbase + 16 * f + kg * 4 + reg;

@@ -39,10 +39,10 @@
 //                 kern_spa2.h, fed from the series), tail probabilities, SE, the output row
 
 // waves of spa4_moments' one workgroup per CU: 12 = three per SIMD at 168 registers (measured at C3:
-// 8 waves 1.74 ms for the whole stage, 12 waves 1.57; 16 would need 128 registers and spill)
-#ifndef SPA4_WAVES
-#define SPA4_WAVES 12
-#endif
+// 8 waves 1.74 ms for the whole stage, 12 waves 1.57; 16 would need 128 registers and spill).  With many
+// covariates a wave's state (c[K], a table row per carrier in flight) no longer fits 168: K = 13 ran
+// 2.56 ms at 8 waves and 3.24 at 12.
+__host__ __device__ constexpr int spa4_waves(int K) { return K <= 8 ? 12 : 8; }
 #define SPA4_NCA 12              /* cumulants carried for the variants of tier A (small g t: most carriers) */
 #define SPA4_NCB SPA4_NC         /* ... of tier B */
 #define SPA4_NSMAX (SPA4_NC + 5) /* partial sums per (variant, segment) of the wider tier */
@@ -121,12 +121,12 @@ __device__ __forceinline__ int wave_reduce_scatter(double (&x)[V], int lane)
 #define SPA4_VPER 128            /* flagged variants whose parameters a workgroup holds in LDS at a time */
 
 // entries of a wave's leftover queue
-__host__ __device__ constexpr int spa4_qcap(int K) { return spa_seg(K) / 2 < 8192 / SPA4_WAVES ? spa_seg(K) / 2 : (8192 / SPA4_WAVES) & ~63; }
+__host__ __device__ constexpr int spa4_qcap(int K) { return spa_seg(K) / 2 < 8192 / spa4_waves(K) ? spa_seg(K) / 2 : (8192 / spa4_waves(K)) & ~63; }
 
 // dynamic LDS of spa4_moments<K>: the segment's table + the parameter slice + a queue per wave
 __host__ __device__ constexpr size_t spa4_lds_bytes(int K)
 {
-	return (size_t)spa_seg(K) * ((K + 2) & ~1) * 8 + (size_t)SPA4_VPER * (8 + 8 * (K + 6)) + (size_t)SPA4_WAVES * spa4_qcap(K) * 2;
+	return (size_t)spa_seg(K) * ((K + 2) & ~1) * 8 + (size_t)SPA4_VPER * (8 + 8 * (K + 6)) + (size_t)spa4_waves(K) * spa4_qcap(K) * 2;
 }
 
 // The flagged variants of a call sit in recs[] in two ranges: tier A from slot 0 upwards (counters[0]
@@ -137,7 +137,7 @@ __device__ __forceinline__ int spa4_rec(int tier, int btop, int v) { return tier
 // rows and mu and the slice's parameters are staged in LDS; one wave per variant, a lane owns SEG/64
 // consecutive samples of the segment and walks its carriers in lock step with the other lanes.
 template <int K, int NC>
-__global__ void __launch_bounds__(WAVE * SPA4_WAVES)
+__global__ void __launch_bounds__(WAVE * spa4_waves(K))
 spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg, int tier, int btop, int v0, int vcap,
 	const SpaRec *__restrict__ recs, const int *__restrict__ counters, double *__restrict__ segpart, int abl)
 {
@@ -181,12 +181,12 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 			const int rows = min(SEG, N - seg * SEG);
 			const double2 *src = reinterpret_cast<const double2 *>(md.XM + (size_t)seg * SEG * KP);
 			double2 *dst = reinterpret_cast<double2 *>(tab);
-			for (int i = tid; i < rows * (KP / 2); i += WAVE * SPA4_WAVES) dst[i] = src[i];
+			for (int i = tid; i < rows * (KP / 2); i += WAVE * spa4_waves(K)) dst[i] = src[i];
 			row_off = ((size_t)seg * (SEG / 16) + (size_t)lane * LDW) * 4;
 			mine = lane < NLANE && row_off + 4 * LDW <= bpv;
 			samp0 = seg * SEG + lane * LDW * 16;
 		}
-		for (int i = tid; i < nv; i += WAVE * SPA4_WAVES) {
+		for (int i = tid; i < nv; i += WAVE * spa4_waves(K)) {
 			const SpaRec &r = recs[spa4_rec(tier, btop, v0 + vb + i)];
 			pj[i] = r.j;
 			pj[SPA4_VPER + i] = r.minus ? (int)0xAAAAAAAAu : 0;
@@ -201,11 +201,11 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 		// rows two variants ahead of the one being worked on
 		uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0;
 		if (wid < nv) w0 = load_row(wid);
-		if (wid + SPA4_WAVES < nv) w1 = load_row(wid + SPA4_WAVES);
-		for (int vl = wid; vl < nv; vl += SPA4_WAVES) {
+		if (wid + spa4_waves(K) < nv) w1 = load_row(wid + spa4_waves(K));
+		for (int vl = wid; vl < nv; vl += spa4_waves(K)) {
 			const uint4 wv = w0;
 			w0 = w1;
-			if (vl + 2 * SPA4_WAVES < nv) w1 = load_row(vl + 2 * SPA4_WAVES);
+			if (vl + 2 * spa4_waves(K) < nv) w1 = load_row(vl + 2 * spa4_waves(K));
 			const double inv = pd[vl], ts = pd[SPA4_VPER + vl];
 			const uint32_t zx = (uint32_t)pj[SPA4_VPER + vl];
 			double c[K];
@@ -334,7 +334,7 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 // dosages is dense -- nearly every sample is a "carrier" -- so there is nothing to compact: in step j
 // lane l takes sample 64 j + l of the segment (coalesced row loads), skipping the exact zeros.
 template <int K, int NC, int INPUT>
-__global__ void __launch_bounds__(WAVE * SPA4_WAVES)
+__global__ void __launch_bounds__(WAVE * spa4_waves(K))
 spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, int nseg, int tier, int btop, int v0, int vcap,
 	const SpaRec *__restrict__ recs, const int *__restrict__ counters, double *__restrict__ segpart)
 {
@@ -359,9 +359,9 @@ spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, in
 			const int nrow = min(SEG, N - seg * SEG);
 			const double2 *src = reinterpret_cast<const double2 *>(md.XM + (size_t)seg * SEG * KP);
 			double2 *dst = reinterpret_cast<double2 *>(tab);
-			for (int i = tid; i < nrow * (KP / 2); i += WAVE * SPA4_WAVES) dst[i] = src[i];
+			for (int i = tid; i < nrow * (KP / 2); i += WAVE * spa4_waves(K)) dst[i] = src[i];
 		}
-		for (int i = tid; i < nv; i += WAVE * SPA4_WAVES) {
+		for (int i = tid; i < nv; i += WAVE * spa4_waves(K)) {
 			const SpaRec &r = recs[spa4_rec(tier, btop, v0 + vb + i)];
 			pj[i] = r.j;
 			pj[SPA4_VPER + i] = r.minus;
@@ -374,7 +374,7 @@ spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, in
 		}
 		__syncthreads();
 		const int s_lo = seg * SEG, nstep = (min(SEG, N - s_lo) + WAVE - 1) / WAVE;
-		for (int vl = wid; vl < nv; vl += SPA4_WAVES) {
+		for (int vl = wid; vl < nv; vl += spa4_waves(K)) {
 			const double inv = pd[vl], ts = pd[SPA4_VPER + vl];
 			const double imp = pd[(2 + K + 3) * SPA4_VPER + vl];      // lut[3]: the imputed value, flipped already
 			const bool minus = pj[SPA4_VPER + vl] != 0;

@@ -531,12 +531,13 @@ static int ensure_recs(sgx_handle *h, size_t n)
 
 #define FOR_EACH_K(X) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16)
 
-// Sample splits of the MFMA kernels: a few rounds of 2 workgroups per CU, and a multiple of
-// 8 splits when there are that many, so that each XCD works on whole splits (kern_score_mfma.h)
-static dim3 mf_grid(int n_cu, size_t rows, int ntile, int *tps)
+// Sample splits of the MFMA kernels: a few rounds of the workgroups a CU holds (wg_per_cu), and a
+// multiple of 8 splits when there are that many, so that each XCD works on whole splits
+// (kern_score_mfma.h).  vpb: variants per workgroup.
+static dim3 mf_grid(int n_cu, size_t rows, int ntile, int *tps, int vpb = MF_VPB, int wg_per_cu = 2)
 {
-	const int vt = (int)((rows + MF_VPB - 1) / MF_VPB);
-	int sk = std::max(1, (n_cu * 2 * 4 + vt / 2) / vt);
+	const int vt = (int)((rows + vpb - 1) / vpb);
+	int sk = std::max(1, (n_cu * wg_per_cu * 4 + vt / 2) / vt);
 	sk = std::min(sk, std::max(1, ntile / 24));   // a split shorter than ~24 tiles is mostly prologue and atomics
 	if (sk >= 6) sk = (sk + 7) & ~7;
 	sk = std::min(sk, std::max(1, ntile / 2));
@@ -560,24 +561,27 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	if (use_mf) {
 		const MfEpi &ep = h->mfe;
 		HIPCHK(hipMemsetAsync(h->mf_acc, 0, M * (size_t)ep.acc_stride * sizeof(int), st));
-		int tps = 0;
-		const dim3 mgrid = mf_grid(h->n_cu, M, h->mf[0].ntile, &tps);
-		// wide rows where the registers allow it (4 value fragments + two row pieces would spill)
+		// wide rows where the registers allow it
 		const bool wide = row_bytes % 128 == 0 && (size_t)h->mf[0].ntile * 64 <= row_bytes;
 		for (int g = 0; g < ep.ngroups; g++) {
 			const size_t lds = (size_t)2 * 16 * ep.gncol[g] * 16;
 			int *acc = h->mf_acc + ep.goff[g];
-#define MFRUN(NB, B1)                                                                          \
-	do { if (wide && NB <= 3) hipLaunchKernelGGL((score_mfma_kernel<(NB <= 3 ? NB : 3), B1, true>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
-			(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride);      \
-		else hipLaunchKernelGGL((score_mfma_kernel<NB, B1, false>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
+			// NAF_ = 3 A fragments per wave: 3 waves per SIMD (<= 168 registers) instead of 2 -- 6 % faster at
+			// K = 3 although each B fragment read then feeds 3 MFMAs instead of 4; used wherever it fits
+			// without spilling (not: 4 value fragments + bit-1 fragment; 3 + bit-1 only with narrow rows)
+#define MFRUN(NB, B1, WIDE_, NAF_)                                                             \
+	do { int tps = 0;                                                                          \
+		const dim3 mgrid = mf_grid(h->n_cu, M, h->mf[g].ntile, &tps, 16 * NAF_ * MF_WAVES, NAF_ == 3 ? 3 : 2); \
+		hipLaunchKernelGGL((score_mfma_kernel<NB, B1, WIDE_, 0, NAF_>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
 			(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride); } while (0)
 			const int nb = h->mf_nbfv[g];
 			if (g == 0) {
-				if (nb == 2) MFRUN(2, true); else if (nb == 3) MFRUN(3, true); else MFRUN(4, true);
+				if (nb == 2) { if (wide) MFRUN(2, true, true, 3); else MFRUN(2, true, false, 3); }
+				else if (nb == 3) MFRUN(3, true, false, 3);
+				else MFRUN(4, true, false, 4);
 			} else {
-				if (nb == 1) MFRUN(1, false); else if (nb == 2) MFRUN(2, false);
-				else if (nb == 3) MFRUN(3, false); else MFRUN(4, false);
+				if (nb == 1) MFRUN(1, false, false, 3); else if (nb == 2) MFRUN(2, false, false, 3);
+				else if (nb == 3) MFRUN(3, false, false, 3); else MFRUN(4, false, false, 3);
 			}
 #undef MFRUN
 		}
@@ -643,12 +647,12 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 #define MOMENTS(KK, NCX, TIER, RD)                                                               \
 	do {                                                                                         \
 		if (INPUT == IN_2BIT)                                                                    \
-			hipLaunchKernelGGL((spa4_moments<KK, NCX>), dim3((unsigned)(h->n_cu * (SPA4_WAVES <= 8 ? 8 / SPA4_WAVES : 1))), \
-				dim3(WAVE * SPA4_WAVES), fl, st, (const uint8_t *)rows, row_bytes, md, h->nseg,  \
+			hipLaunchKernelGGL((spa4_moments<KK, NCX>), dim3((unsigned)h->n_cu), \
+				dim3(WAVE * spa4_waves(KK)), fl, st, (const uint8_t *)rows, row_bytes, md, h->nseg,  \
 				TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl); \
 		else                                                                                     \
 			hipLaunchKernelGGL((spa4_moments_ds<KK, NCX, (INPUT == IN_2BIT ? IN_U8 : INPUT)>),   \
-				dim3((unsigned)(h->n_cu * (SPA4_WAVES <= 8 ? 8 / SPA4_WAVES : 1))), dim3(WAVE * SPA4_WAVES), fl, st, rows, row_bytes, md, \
+				dim3((unsigned)h->n_cu), dim3(WAVE * spa4_waves(KK)), fl, st, rows, row_bytes, md, \
 				h->nseg, TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4);  \
 		hipLaunchKernelGGL((spa4_solve<KK, NCX>), gsolve, dim3(256), 0, st, md, h->nseg, TIER,   \
 			btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->fallback,         \

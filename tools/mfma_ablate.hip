@@ -19,9 +19,10 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 
-template <int ABL, bool WIDE = false>
+template <int ABL, bool WIDE = false, int NAF = 4>
 static float run(const uint8_t *G, size_t bpv, int M, const MfTab &tb, dim3 grid, int tps, int *acc, int reps)
 {
+	grid.x = (M + 16 * NAF * MF_WAVES - 1) / (16 * NAF * MF_WAVES);
 	hipEvent_t a, b;
 	(void)hipEventCreate(&a); (void)hipEventCreate(&b);
 	const size_t lds = (size_t)2 * 16 * 64 * 16 + ((ABL & 512) ? 16 * 1024 : 0);
@@ -29,7 +30,7 @@ static float run(const uint8_t *G, size_t bpv, int M, const MfTab &tb, dim3 grid
 	for (int r = 0; r < reps + 1; r++) {
 		(void)hipMemsetAsync(acc, 0, (size_t)M * (64 + 48) * sizeof(int), 0);
 		(void)hipEventRecord(a, 0);
-		hipLaunchKernelGGL((score_mfma_kernel<3, true, WIDE, ABL>), grid, dim3(WAVE * MF_WAVES), lds, 0, G, bpv, M, tb, tps, acc, 64 + 48);
+		hipLaunchKernelGGL((score_mfma_kernel<3, true, WIDE, ABL, NAF>), grid, dim3(WAVE * MF_WAVES), lds, 0, G, bpv, M, tb, tps, acc, 64 + 48);
 		(void)hipEventRecord(b, 0);
 		(void)hipEventSynchronize(b);
 		float ms = 0;
@@ -98,6 +99,14 @@ int main(int argc, char **argv)
 #define RUNW(A, what) { const float ms = run<A, true>(G, bpv, M, tb, grid, tps, acc, reps); \
 	printf("ABL=%2d wide rows: %-22s %7.3f ms  %6.0f GB/s\n", A, what, ms, (double)M * bpv / ms / 1e6); }
 	if (tps % 2 == 0 && tb.ntile % 2 == 0) {
+#define RUN3(A, W, what) { const float ms = run<A, W, 3>(G, bpv, M, tb, grid, tps, acc, reps); \
+	printf("ABL=%2d 3 A fragments, 3 waves/SIMD%s: %-22s %7.3f ms  %6.0f GB/s\n", A, W ? ", wide" : "", what, ms, (double)M * bpv / ms / 1e6); }
+		RUN3(0, false, "product kernel")
+		RUN3(1, false, "- missing plane")
+		RUN3(64, false, "memory system only")
+		RUN3(0, true, "product kernel")
+		RUN3(1, true, "- missing plane")
+		RUN3(64, true, "memory system only")
 		RUNW(0, "product kernel")
 		RUNW(1, "- missing plane")
 		RUNW(64, "memory system only")
