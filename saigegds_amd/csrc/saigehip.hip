@@ -514,7 +514,9 @@ static int ensure_recs(sgx_handle *h, size_t n)
 		HIPCHK(hipMalloc((void **)&h->fb_x2, n * sizeof(int)));
 		if (h->seg4) HIPCHK(hipFree(h->seg4));
 		h->seg4 = nullptr;
-		h->vcap4 = (int)std::min<size_t>(n, 32768);       // flagged variants per round of the series SPA stage
+		// flagged variants per round of the series SPA stage: a block of the usual 50 000 variants in one
+		// round (a second, normally empty round costs four kernel launches per step)
+		h->vcap4 = (int)std::min<size_t>(n, 65536);
 		h->nround4 = (int)((n + h->vcap4 - 1) / h->vcap4);
 		HIPCHK(hipMalloc((void **)&h->seg4, (size_t)h->nseg * SPA4_NSMAX * h->vcap4 * sizeof(double)));
 	}

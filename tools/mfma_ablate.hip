@@ -101,6 +101,12 @@ int main(int argc, char **argv)
 	if (tps % 2 == 0 && tb.ntile % 2 == 0) {
 #define RUN3(A, W, what) { const float ms = run<A, W, 3>(G, bpv, M, tb, grid, tps, acc, reps); \
 	printf("ABL=%2d 3 A fragments, 3 waves/SIMD%s: %-22s %7.3f ms  %6.0f GB/s\n", A, W ? ", wide" : "", what, ms, (double)M * bpv / ms / 1e6); }
+#define RUN2(A, W, what) { const float ms = run<A, W, 2>(G, bpv, M, tb, grid, tps, acc, reps); \
+	printf("ABL=%2d 2 A fragments, 4 waves/SIMD%s: %-22s %7.3f ms  %6.0f GB/s\n", A, W ? ", wide" : "", what, ms, (double)M * bpv / ms / 1e6); }
+		RUN2(0, false, "product kernel")
+		RUN2(1, false, "- missing plane")
+		RUN2(64, false, "memory system only")
+		RUN2(0, true, "product kernel")
 		RUN3(0, false, "product kernel")
 		RUN3(1, false, "- missing plane")
 		RUN3(64, false, "memory system only")
