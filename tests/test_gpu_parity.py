@@ -84,7 +84,7 @@ def test_synthetic_flip_missing(trait, prev):
     assert_table_close(out, valid, ref, ref_valid, quant=sm.quant, what=f"synthetic {trait}")
 
 
-@pytest.mark.parametrize("k", [1, 2, 5, 8, 13, 16])
+@pytest.mark.parametrize("k", [1, 2, 4, 5, 8, 9, 13, 16])
 def test_covariate_counts(k):
     sm, packed = _synthetic_case(2000, 400, "binary", 0.1, seed=11 + k, k=k)
     ref, ref_valid = _oracle(sm).scan_2bit(packed)
