@@ -117,7 +117,7 @@ __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 //   1024 s_memtime stamps per tile, 2048 all loads and DMA of a tile issued in one burst at its start
 // NAF: A fragments per wave.  4 (2 waves per SIMD at <= 256 registers) or 3 (3 waves per SIMD at <= 168).
 template <int NBFV, bool HAS_B1, bool WIDE = false, int ABL = 0, int NAF = MF_NAF>
-__global__ void __launch_bounds__(WAVE * MF_WAVES, (NAF == 4 ? 8 : NAF == 3 ? 12 : 16) / MF_WAVES)
+__global__ void __launch_bounds__(WAVE * MF_WAVES, NAF == 4 ? 2 : NAF == 3 ? 3 : 4)   /* waves per SIMD */
 score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab tb,
 	int tiles_per_split, int *__restrict__ accbuf, int acc_stride)
 {
