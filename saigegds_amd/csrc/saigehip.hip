@@ -352,13 +352,29 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 			if (range > 16384.0) nl = MF_NLIMB;
 			return nl;
 		};
+		// Column groups, filled in order (a column is never cut).  Group 0 also carries the bit-1 fragment:
+		// with 3 value fragments it runs the 3-waves-per-SIMD form of the kernel, with 4 the slower
+		// 2-waves one -- so when more than one group is needed anyway, group 0 is filled to 48 columns only,
+		// unless that costs an extra group (an extra pass over the rows).
+		int nlimb[MF_MAXP];
+		for (int c : order) nlimb[c] = limbs_for(c);
 		int g = 0, used = 1, glimbs[MF_MAXG] = {0};   // group 0: one column for the constant 1
-		for (int c : order) {
-			const int nl = limbs_for(c);
-			if (used + nl > MF_GLIMBS) { glimbs[g] = used; g++; used = 0; }
-			if (g >= MF_MAXG) { range_ok = false; break; }
-			ep.cgrp[c] = (unsigned char)g; ep.ccol[c] = (unsigned char)(used - (g == 0 ? 1 : 0)); ep.climb[c] = (unsigned char)nl;
-			used += nl;
+		auto plan = [&](int cap0, bool commit) -> int {
+			int gg = 0, uu = 1;
+			for (int c : order) {
+				const int nl = nlimb[c];
+				if (uu + nl > (gg == 0 ? cap0 : MF_GLIMBS)) { if (commit) glimbs[gg] = uu; gg++; uu = 0; }
+				if (gg >= MF_MAXG) return MF_MAXG + 1;
+				if (commit) { ep.cgrp[c] = (unsigned char)gg; ep.ccol[c] = (unsigned char)(uu - (gg == 0 ? 1 : 0)); ep.climb[c] = (unsigned char)nl; }
+				uu += nl;
+			}
+			if (commit) { g = gg; used = uu; }
+			return gg + 1;
+		};
+		{
+			const int n64 = plan(MF_GLIMBS, false), n48 = plan(48, false);
+			const int cap0 = (n64 > 1 && n48 == n64) ? 48 : MF_GLIMBS;
+			if (plan(cap0, true) > MF_MAXG) range_ok = false;
 		}
 		if (range_ok) {
 		glimbs[g] = used;
