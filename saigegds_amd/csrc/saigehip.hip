@@ -715,10 +715,12 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 			}                                                                                \
 			const int fx5 = (h->force_exact ? 1 : 0) | (h->spa_abl & ~1);                    \
 			if (small5) {                                                                    \
-				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 0, 128>), dim3((unsigned)h->nwg5), dim3(128), \
+				/* (2-bit rows only: the constant keeps the other inputs' 128-thread forms uninstantiated) */ \
+				constexpr int IN5 = INPUT == IN_2BIT ? INPUT : IN_2BIT;                      \
+				hipLaunchKernelGGL((spa5_kernel<KK, IN5, 0, 128>), dim3((unsigned)h->nwg5), dim3(128), \
 					l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
 					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
-				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 1, 128>), dim3((unsigned)h->nwg5), dim3(128), \
+				hipLaunchKernelGGL((spa5_kernel<KK, IN5, 1, 128>), dim3((unsigned)h->nwg5), dim3(128), \
 					l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
 					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
 			} else {                                                                         \
