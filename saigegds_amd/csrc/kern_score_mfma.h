@@ -114,6 +114,7 @@ __device__ __forceinline__ void mf_unpack(uint32_t w, v4i &val, v4i &b1)
 // ABL: switches of the timing tool tools/mfma_ablate.hip (wrong results; the product uses 0):
 //   1 no missing plane, 2 no bit-1 MFMA, 4 no unpack, 16 no A loads, 32 no B DMA,
 //   64 no arithmetic at all (loads, DMA, LDS reads and barriers only),
+//   512 row loads in the pattern of a tiled layout (narrow rows only; the data is then not the variants'),
 //   1024 s_memtime stamps per tile, 2048 all loads and DMA of a tile issued in one burst at its start
 // NAF: A fragments per wave.  4 (2 waves per SIMD at <= 256 registers) or 3 (3 waves per SIMD at <= 168).
 template <int NBFV, bool HAS_B1, bool WIDE = false, int ABL = 0, int NAF = MF_NAF>
@@ -163,8 +164,14 @@ score_mfma_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, MfTab t
 #pragma unroll
 	for (int f = 0; f < NAF; f++)
 		rowp[f] = packed + (size_t)min(vbase + 16 * f + r, M - 1) * bpv + (size_t)t0 * 64 + 16 * kg;
+	int tcur_abl = t0;
 	auto load_A1 = [&](uint4 &dst, int f, int piece) {
 		if (ABL & 16) { dst = make_uint4(t0 + f, lane, wid, 0x01010101u); return; }
+		if (ABL & 512) {   // timing only: the access pattern of a tiled layout (one contiguous KiB per fragment and tile)
+			dst = *reinterpret_cast<const uint4 *>(packed + ((size_t)tcur_abl * ((M + 15) / 16) + (vbase / 16 + f)) * 1024 + lane * 16);
+			if (f == NAF - 1) tcur_abl++;
+			return;
+		}
 		dst = *reinterpret_cast<const uint4 *>(rowp[f] + 64 * piece);
 		if (piece == AW - 1) rowp[f] += 64 * AW;
 	};

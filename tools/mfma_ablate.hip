@@ -110,6 +110,9 @@ int main(int argc, char **argv)
 		RUN3(0, false, "product kernel")
 		RUN3(1, false, "- missing plane")
 		RUN3(64, false, "memory system only")
+		RUN3(512, false, "tiled row loads")
+		RUN3(513, false, "tiled, - missing plane")
+		RUN3(576, false, "tiled, memory system only")
 		RUN3(0, true, "product kernel")
 		RUN3(1, true, "- missing plane")
 		RUN3(64, true, "memory system only")
