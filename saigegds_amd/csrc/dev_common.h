@@ -278,7 +278,7 @@ __device__ __forceinline__ VarHead make_head(const DevModel &md, double AC, int 
 // Series SPA stage (kern_spa4.h): a flagged variant starts in tier A (short series) while the predicted
 // max_i |g_i t| is small: t ~ 1.5 x the first Newton point, |g_i| <= (2 + sum_k |c'_k| max_i |X_ik|) / sqrt(AC2).
 #define SPA4_TIER_X 0.45
-#define SPA5_NNZ 16384           /* variants with at most this many carriers go to the per-variant kernels */
+#define SPA5_NNZ 8192            /* variants with at most this many carriers go to the per-variant kernels (measured: N = 430 000 equal from 4 096 to 16 384, slower below; N = 50 000 best from 1 024 to 8 192, 9 % over 16 384) */
 #define SPA5_EXACT_X 1.2         /* ... and straight to the exact sweeps beyond this predicted max |g t| */
 // 0, 1: tiers A, B of the per-segment moments kernels;  2: per-variant kernel, series on the list;
 // 3: per-variant kernel, exact exp/log sweeps
