@@ -118,7 +118,18 @@ __device__ __forceinline__ int wave_reduce_scatter(double (&x)[V], int lane)
 	return (WIDE && (lane & 6) == 6) ? 24 : idx;
 }
 
-#define SPA4_VPER 128            /* flagged variants whose parameters a workgroup holds in LDS at a time */
+#define SPA4_VPER 128            /* flagged variants whose parameters a workgroup holds in LDS at a time (at most) */
+
+// Variants per item: SPA4_VPER when that still gives every workgroup a few (segment, slice) items; with few
+// segments (N = 50 000: 13) smaller slices, whole rounds of the workgroup's waves, so that the items
+// outnumber the workgroups ~4 to 1 (with 128 the 143 items of a C2 block left 113 of 256 CUs idle).
+__device__ __forceinline__ int spa4_slice(int nflag, int nseg, int nwg, int waves)
+{
+	const int want = (4 * nwg + nseg - 1) / nseg;                      // slices wanted
+	int v = (nflag + want - 1) / want;
+	v = (v + waves - 1) / waves * waves;
+	return min(SPA4_VPER, max(v, waves));
+}
 
 // entries of a wave's leftover queue
 __host__ __device__ constexpr int spa4_qcap(int K) { return spa_seg(K) / 2 < 8192 / spa4_waves(K) ? spa_seg(K) / 2 : (8192 / spa4_waves(K)) & ~63; }
@@ -155,7 +166,8 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 	if (nflag <= 0) return;
 	// the (segment, slice) items in segment-major order, an equal contiguous share per workgroup:
 	// a workgroup restages the table only when its range crosses into the next segment
-	const int nslice = (nflag + SPA4_VPER - 1) / SPA4_VPER;
+	const int vper = spa4_slice(nflag, nseg, gridDim.x, spa4_waves(K));
+	const int nslice = (nflag + vper - 1) / vper;
 	const long long nitem = (long long)nseg * nslice;
 	const int it0 = (int)(nitem * blockIdx.x / gridDim.x), it1 = (int)(nitem * (blockIdx.x + 1) / gridDim.x);
 	int seg = -1;
@@ -173,8 +185,8 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 		return w;
 	};
 	for (int it = it0; it < it1; it++) {
-		const int sg = it / nslice, vb = (it - sg * nslice) * SPA4_VPER;
-		const int nv = min(SPA4_VPER, nflag - vb);
+		const int sg = it / nslice, vb = (it - sg * nslice) * vper;
+		const int nv = min(vper, nflag - vb);
 		__syncthreads();                     // the previous item's readers are done
 		if (sg != seg) {
 			seg = sg;
@@ -346,13 +358,14 @@ spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, in
 	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
 	const int nflag = min(counters[tier ? 7 : 0] - v0, vcap);
 	if (nflag <= 0) return;
-	const int nslice = (nflag + SPA4_VPER - 1) / SPA4_VPER;
+	const int vper = spa4_slice(nflag, nseg, gridDim.x, spa4_waves(K));
+	const int nslice = (nflag + vper - 1) / vper;
 	const long long nitem = (long long)nseg * nslice;
 	const int it0 = (int)(nitem * blockIdx.x / gridDim.x), it1 = (int)(nitem * (blockIdx.x + 1) / gridDim.x);
 	int seg = -1;
 	for (int it = it0; it < it1; it++) {
-		const int sg = it / nslice, vb = (it - sg * nslice) * SPA4_VPER;
-		const int nv = min(SPA4_VPER, nflag - vb);
+		const int sg = it / nslice, vb = (it - sg * nslice) * vper;
+		const int nv = min(vper, nflag - vb);
 		__syncthreads();                     // the previous item's readers are done
 		if (sg != seg) {
 			seg = sg;
