@@ -144,13 +144,23 @@ __host__ __device__ constexpr size_t spa4_lds_bytes(int K)
 // of them), tier B from slot btop - 1 downwards (counters[7]); rec index of the v-th of a tier:
 __device__ __forceinline__ int spa4_rec(int tier, int btop, int v) { return tier ? btop - 1 - v : v; }
 
+// The last workgroup to leave a moments kernel puts the item queue back to zero for the next launch on the
+// stream: cursor[0] = next item, cursor[1] = workgroups that are through.
+__device__ __forceinline__ void spa4_queue_done(int *cursor)
+{
+	if (threadIdx.x == 0 && atomicAdd(cursor + 1, 1) == (int)gridDim.x - 1) {
+		__hip_atomic_store(cursor, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		__hip_atomic_store(cursor + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	}
+}
+
 // One workgroup per CU.  Item = (sample segment, slice of SPA4_VPER flagged variants): the segment's X
 // rows and mu and the slice's parameters are staged in LDS; one wave per variant, a lane owns SEG/64
 // consecutive samples of the segment and walks its carriers in lock step with the other lanes.
 template <int K, int NC>
 __global__ void __launch_bounds__(WAVE * spa4_waves(K))
 spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg, int tier, int btop, int v0, int vcap,
-	const SpaRec *__restrict__ recs, const int *__restrict__ counters, double *__restrict__ segpart, int abl)
+	const SpaRec *__restrict__ recs, const int *__restrict__ counters, double *__restrict__ segpart, int abl, int *__restrict__ cursor)
 {
 	constexpr int SEG = spa_seg(K), KP = (K + 2) & ~1, NS = NC + 5;
 	constexpr int LDW = SEG / 16 / WAVE > 0 ? SEG / 16 / WAVE : 1;     // dwords (of 16 samples) per lane
@@ -164,12 +174,13 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 	uint16_t *q = reinterpret_cast<uint16_t *>(pj + 2 * SPA4_VPER) + wid * spa4_qcap(K);      // this wave's queue: sample in the segment | code << 14
 	const int nflag = min(counters[tier ? 7 : 0] - v0, vcap);
 	if (nflag <= 0) return;
-	// the (segment, slice) items in segment-major order, an equal contiguous share per workgroup:
-	// a workgroup restages the table only when its range crosses into the next segment
+	// the (segment, slice) items in segment-major order, pulled off a queue (cursor[0]): the items differ in
+	// weight (carriers per slice) and a static share left workgroups idle behind the slowest; the workgroups
+	// running at any moment work on the same few segments, so the tables they restage come from L2
 	const int vper = spa4_slice(nflag, nseg, gridDim.x, spa4_waves(K));
 	const int nslice = (nflag + vper - 1) / vper;
-	const long long nitem = (long long)nseg * nslice;
-	const int it0 = (int)(nitem * blockIdx.x / gridDim.x), it1 = (int)(nitem * (blockIdx.x + 1) / gridDim.x);
+	const int nitem = nseg * nslice;
+	__shared__ int sh_it;
 	int seg = -1;
 	size_t row_off = 0;                                                           // this lane's bytes of a row
 	bool mine = false;
@@ -184,10 +195,14 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 		}
 		return w;
 	};
-	for (int it = it0; it < it1; it++) {
+	for (;;) {
+		__syncthreads();                     // the previous item's readers are done
+		if (tid == 0) sh_it = atomicAdd(cursor, 1);
+		__syncthreads();
+		const int it = sh_it;
+		if (it >= nitem) break;
 		const int sg = it / nslice, vb = (it - sg * nslice) * vper;
 		const int nv = min(vper, nflag - vb);
-		__syncthreads();                     // the previous item's readers are done
 		if (sg != seg) {
 			seg = sg;
 			const int rows = min(SEG, N - seg * SEG);
@@ -340,6 +355,7 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 			if (lane == 1) segpart[base + (size_t)(NS - 1) * vcap] = gmax;
 		}
 	}
+	spa4_queue_done(cursor);
 }
 
 // Dosage rows (RAW bytes / doubles, kern_spa.h load_dosage): the same sums, but a row of imputed
@@ -348,7 +364,7 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 template <int K, int NC, int INPUT>
 __global__ void __launch_bounds__(WAVE * spa4_waves(K))
 spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, int nseg, int tier, int btop, int v0, int vcap,
-	const SpaRec *__restrict__ recs, const int *__restrict__ counters, double *__restrict__ segpart)
+	const SpaRec *__restrict__ recs, const int *__restrict__ counters, double *__restrict__ segpart, int *__restrict__ cursor)
 {
 	constexpr int SEG = spa_seg(K), KP = (K + 2) & ~1, NS = NC + 5;
 	extern __shared__ __attribute__((aligned(16))) uint8_t fill_smem[];
@@ -360,13 +376,17 @@ spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, in
 	if (nflag <= 0) return;
 	const int vper = spa4_slice(nflag, nseg, gridDim.x, spa4_waves(K));
 	const int nslice = (nflag + vper - 1) / vper;
-	const long long nitem = (long long)nseg * nslice;
-	const int it0 = (int)(nitem * blockIdx.x / gridDim.x), it1 = (int)(nitem * (blockIdx.x + 1) / gridDim.x);
+	const int nitem = nseg * nslice;
+	__shared__ int sh_it;
 	int seg = -1;
-	for (int it = it0; it < it1; it++) {
+	for (;;) {
+		__syncthreads();                     // the previous item's readers are done
+		if (tid == 0) sh_it = atomicAdd(cursor, 1);
+		__syncthreads();
+		const int it = sh_it;
+		if (it >= nitem) break;
 		const int sg = it / nslice, vb = (it - sg * nslice) * vper;
 		const int nv = min(vper, nflag - vb);
-		__syncthreads();                     // the previous item's readers are done
 		if (sg != seg) {
 			seg = sg;
 			const int nrow = min(SEG, N - seg * SEG);
@@ -438,6 +458,7 @@ spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, in
 			if (lane == 1) segpart[base + (size_t)(NS - 1) * vcap] = gmax;
 		}
 	}
+	spa4_queue_done(cursor);
 }
 
 // the carrier series of one variant

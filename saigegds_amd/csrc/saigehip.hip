@@ -265,7 +265,7 @@ static int alloc_workspace(sgx_handle *h)
 		// short (128-thread workgroups, see the launch), else one
 		h->nwg5 = (size_t)((N + 63) / 64) * 16 <= 32 * 1024 ? h->n_cu * 4 : h->n_cu;
 		HIPCHK(hipMalloc((void **)&h->scr5, (size_t)h->nwg5 * spa5_wg_bytes(N)));
-		HIPCHK(hipMalloc((void **)&h->cur5, 2 * sizeof(int)));
+		HIPCHK(hipMalloc((void **)&h->cur5, 4 * sizeof(int)));   // [0], [1] spa5_kernel queues; [2], [3] spa4_moments' item queue
 	}
 	return SGX_OK;
 }
@@ -573,7 +573,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	constexpr int SB = 256, PB = 512;
 	hipStream_t st = h->stream;
 	HIPCHK(hipMemsetAsync(h->counters, 0, 24 * sizeof(int), st));
-	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 2 * sizeof(int), st));
+	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 4 * sizeof(int), st));
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	const bool use_mf = (INPUT == IN_2BIT) && h->mf_ok && !h->force_v1;
 	if (use_mf) {
@@ -667,11 +667,11 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 		if (INPUT == IN_2BIT)                                                                    \
 			hipLaunchKernelGGL((spa4_moments<KK, NCX>), dim3((unsigned)h->n_cu), \
 				dim3(WAVE * spa4_waves(KK)), fl, st, (const uint8_t *)rows, row_bytes, md, h->nseg,  \
-				TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl); \
+				TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl, h->cur5 + 2); \
 		else                                                                                     \
 			hipLaunchKernelGGL((spa4_moments_ds<KK, NCX, (INPUT == IN_2BIT ? IN_U8 : INPUT)>),   \
 				dim3((unsigned)h->n_cu), dim3(WAVE * spa4_waves(KK)), fl, st, rows, row_bytes, md, \
-				h->nseg, TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4);  \
+				h->nseg, TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->cur5 + 2);  \
 		hipLaunchKernelGGL((spa4_solve<KK, NCX>), gsolve, dim3(256), 0, st, md, h->nseg, TIER,   \
 			btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->fallback,         \
 			h->fb_spa2, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0);                   \
