@@ -122,10 +122,10 @@ __device__ __forceinline__ int wave_reduce_scatter(double (&x)[V], int lane)
 
 // Variants per item: SPA4_VPER when that still gives every workgroup a few (segment, slice) items; with few
 // segments (N = 50 000: 13) smaller slices, whole rounds of the workgroup's waves, so that the items
-// outnumber the workgroups ~4 to 1 (with 128 the 143 items of a C2 block left 113 of 256 CUs idle).
+// outnumber the workgroups ~8 to 1 (with 128 the 143 items of a C2 block left 113 of 256 CUs idle).
 __device__ __forceinline__ int spa4_slice(int nflag, int nseg, int nwg, int waves)
 {
-	const int want = (4 * nwg + nseg - 1) / nseg;                      // slices wanted
+	const int want = (8 * nwg + nseg - 1) / nseg;                      // slices wanted
 	int v = (nflag + want - 1) / want;
 	v = (v + waves - 1) / waves * waves;
 	return min(SPA4_VPER, max(v, waves));
