@@ -77,6 +77,7 @@ int main(int argc, char **argv)
 	const int vt = (M + MF_VPB - 1) / MF_VPB;
 	int sk = std::max(1, (pr.multiProcessorCount * (8 / MF_WAVES) * 4 + vt / 2) / vt);
 	if (sk >= 6) sk = (sk + 7) & ~7;
+	if (getenv("SK")) sk = atoi(getenv("SK"));
 	sk = std::min(sk, tb.ntile);
 	int tps = (tb.ntile + sk - 1) / sk;
 	tps += tps & 1;
