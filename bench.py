@@ -189,7 +189,7 @@ def main():
 
     # ---- per-kernel figures (rank 0's launches) ----------------------------
     # HIP events recorded by the library on ITS stream around the score stage
-    # (score_mfma_kernel + its 40 us epilogue) and around the SPA stage (spa3_* kernels).
+    # (score_mfma_kernel + its 40 us epilogue) and around the SPA stage (spa4_moments / spa4_solve / spa5_kernel).
     tot, ncalls = sc.stats_total(reset=True)
     assert ncalls == steps, (ncalls, steps)
     # the same kernel with nothing running beside it (one lane, a few extra steps outside the timed region)

@@ -60,7 +60,7 @@ __device__ __forceinline__ void root_step(RootState &s, double NAsigma)
 	s.tnew = tnew; s.phase = 1; s.active = true;
 	// Newton converges quadratically: if the step after this one is predicted to fall under
 	// the tolerance, this evaluation is the last and its point becomes the root, so Korg is
-	// wanted with it (a wrong guess only costs time: spa3_korg covers the rest)
+	// wanted with it (a wrong guess only costs time: one more sweep covers the rest)
 	// Steps shrink like st' ~ C st^2 with C ~ st / st_prev^2 once two steps are known.  A guess on
 	// the generous side is cheap (one log per carrier), a missed one costs a sweep over the list.
 	const double st = fabs(tnew - s.t);

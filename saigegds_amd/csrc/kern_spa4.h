@@ -20,13 +20,19 @@
 // getroot_K1_fast, both roots, and the Lugannani-Rice tail are polynomial evaluations by one thread
 // per variant (spa4_solve).  No carrier list is stored and none is re-read.
 //
-// A variant leaves this path for the exact exp/log kernels (spa2_kernel, then spa_kernel) when
+// A variant leaves this path for the exact exp/log sums (spa5_kernel mode 1 on its carrier list, or the
+// dense spa_kernel) when
 //   * any point the root search evaluates has gmax |t| > spa_xmax (= a quarter of the smallest
 //     convergence radius over the model's mu_i), or
-//   * there the last two terms of the K2 series (the slowest of the three) exceed 1e-13 of its sum, or
-//   * the g_pos / g_neg bound test of kern_spa2.h is not decisive.
-// Those are the rare variants (few carriers, large g): their lists are short and the exact kernels
-// cheap.  Results do not depend on which path a variant takes beyond ~1e-13.
+//   * there the last two terms of the K2 series (the slowest of the three) exceed SPA4_TAIL_TOL of its
+//     sum, or
+//   * the g_pos / g_neg bound test of kern_spa2.h is not decisive (-> spa_kernel).
+// Those are the rare variants (few carriers, large g): their lists are short.  Results do not depend on
+// which path a variant takes beyond ~1e-12 (tests: test_baseline_c3_exact_path_agrees).
+//
+// Variants with at most SPA5_NNZ carriers never enter the per-segment pass: a workgroup per variant
+// (spa5_kernel) builds the carrier list once and runs the same series on it (mode 0), or the exact sweeps
+// where the predicted max |g t| is beyond the series' reach (mode 1).
 //
 //   spa4_moments  workgroups pull (sample segment, slice of the flagged variants) items from a queue;
 //                 the segment's X rows and mu are staged in LDS, then one wave per variant compacts
