@@ -356,9 +356,11 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 			const int idx = wave_reduce_scatter(acc, lane);
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o, WAVE));
-			const size_t base = (size_t)seg * NS * vcap + (vb + vl);
-			if (!(lane & (NS - 1 > 16 ? 1 : 3)) && idx < NS - 1) segpart[base + (size_t)idx * vcap] = acc[0];
-			if (lane == 1) segpart[base + (size_t)(NS - 1) * vcap] = gmax;
+			// [variant][segment][NS]: the sums of a (variant, segment) leave in one store, and spa4_solve reads a
+			// variant's segments as one contiguous run
+			const size_t base = ((size_t)(vb + vl) * nseg + seg) * NS;
+			if (!(lane & (NS - 1 > 16 ? 1 : 3)) && idx < NS - 1) segpart[base + idx] = acc[0];
+			if (lane == 1) segpart[base + (NS - 1)] = gmax;
 		}
 	}
 	spa4_queue_done(cursor);
@@ -459,9 +461,11 @@ spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, in
 			const int idx = wave_reduce_scatter(acc, lane);
 #pragma unroll
 			for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o, WAVE));
-			const size_t base = (size_t)seg * NS * vcap + (vb + vl);
-			if (!(lane & (NS - 1 > 16 ? 1 : 3)) && idx < NS - 1) segpart[base + (size_t)idx * vcap] = acc[0];
-			if (lane == 1) segpart[base + (size_t)(NS - 1) * vcap] = gmax;
+			// [variant][segment][NS]: the sums of a (variant, segment) leave in one store, and spa4_solve reads a
+			// variant's segments as one contiguous run
+			const size_t base = ((size_t)(vb + vl) * nseg + seg) * NS;
+			if (!(lane & (NS - 1 > 16 ? 1 : 3)) && idx < NS - 1) segpart[base + idx] = acc[0];
+			if (lane == 1) segpart[base + (NS - 1)] = gmax;
 		}
 	}
 	spa4_queue_done(cursor);
@@ -551,10 +555,10 @@ __device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int
 #pragma unroll
 	for (int x = 0; x < NS; x++) a[x] = 0;
 	for (int s = lane; s < nseg; s += WAVE) {
-		const double *p = segpart + (size_t)s * NS * vcap + v;
+		const double *p = segpart + ((size_t)v * nseg + s) * NS;
 #pragma unroll
-		for (int x = 0; x < NS - 1; x++) a[x] += p[(size_t)x * vcap];
-		a[NS - 1] = fmax(a[NS - 1], p[(size_t)(NS - 1) * vcap]);
+		for (int x = 0; x < NS - 1; x++) a[x] += p[x];
+		a[NS - 1] = fmax(a[NS - 1], p[NS - 1]);
 	}
 #pragma unroll
 	for (int x = 0; x < NS - 1; x++) a[x] = wave_sum(a[x]);

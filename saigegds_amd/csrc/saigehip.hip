@@ -84,7 +84,7 @@ struct sgx_handle {
 	int nseg = 0;                     // sample segments of the SPA stage
 	bool force_dense = false;         // test hook: every SPA variant takes the exact dense pass
 	// series SPA stage (kern_spa4.h)
-	double *seg4 = nullptr;           // [nseg][NC + 5][vcap4] partial sums of one round of flagged variants
+	double *seg4 = nullptr;           // [vcap4][nseg][NC + 5] partial sums of one round of flagged variants
 	int vcap4 = 0, nround4 = 0;
 	bool spa5_attr_set[3] = {false, false, false};
 	bool mom_attr_set[3] = {false, false, false};   // per input type: the moments kernels' dynamic LDS size has been raised
