@@ -564,7 +564,9 @@ __device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int
 	for (int x = 0; x < NS - 1; x++) a[x] = wave_sum(a[x]);
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) a[NS - 1] = fmax(a[NS - 1], __shfl_xor(a[NS - 1], o, WAVE));
-	if (lane != 0) return;
+	// Lanes 0 and 1 go on with identical values: each runs one of the two root searches (q and 2 m1 - q),
+	// lane 0 collects and writes.
+	if (lane > 1) return;
 	// scalars of saige_main.cpp:369-381
 	const double inv = 1 / sqrt(r.AC2);
 	double xmu_c = 0, xsum_c = 0;
@@ -577,7 +579,7 @@ __device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int
 	const double sdev = qtilde - m1, qinv = -sdev + m1;
 	const double pn_in = d_pchisq1_upper(sdev * sdev / var2);
 	if (fabs(qtilde - m1) / sqrt(var2) < 2.0) {           // SPATest.cpp:319-321 (the score epilogue takes
-		spa_write_row(r, Tstat, var1, pn_in, true, out8);  // these out already; kept for rounding at the edge)
+		if (lane == 0) spa_write_row(r, Tstat, var1, pn_in, true, out8);  // these out already; kept for rounding at the edge)
 		return;
 	}
 	// g_pos / g_neg bound test (kern_spa2.h)
@@ -585,7 +587,7 @@ __device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int
 	const double L = a[2] + fmax(-nb, 0.0), U = a[3] + fmin(-nb, 0.0);
 	const double mar = 1e-9 * (fabs(L) + fabs(U) + fabs(qtilde) + fabs(qinv));
 	if (force_dense || !(qtilde < L - mar && qtilde > U + mar && qinv < L - mar && qinv > U + mar)) {
-		fb_dense[atomicAdd(&counters[2], 1)] = ri;
+		if (lane == 0) fb_dense[atomicAdd(&counters[2], 1)] = ri;
 		return;
 	}
 	Spa4Series<NC> S;
@@ -593,9 +595,16 @@ __device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int
 #pragma unroll
 	for (int x = 0; x < NC - 2; x++) S.kp[x] = a[6 + x];
 	const double NAmu = m1 - a[4], NAsigma = var2 - a[5];
-	RootState s1, s2;
-	if (force_exact || !spa4_root(S, md.spa_xmax, qtilde, NAmu, NAsigma, s1) ||
-		!spa4_root(S, md.spa_xmax, qinv, NAmu, NAsigma, s2)) {
+	const double qmine = lane == 0 ? qtilde : qinv;
+	RootState sm;
+	const bool ok_mine = !force_exact && spa4_root(S, md.spa_xmax, qmine, NAmu, NAsigma, sm);
+	double p_mine = 0;
+	if (ok_mine && sm.converged) p_mine = lugannani_rice(sm.root, sm.Kcur, sm.K2cur, qmine, NAmu, NAsigma);
+	const int st_mine = (ok_mine ? 1 : 0) | (ok_mine && sm.converged ? 2 : 0);
+	const double p_other = __shfl(p_mine, 1, WAVE);         // lane 0 reads lane 1's root
+	const int st_other = __shfl(st_mine, 1, WAVE);
+	if (lane != 0) return;
+	if (!(st_mine & 1) || !(st_other & 1)) {
 		if (tier == 0 && !force_exact) {
 			const int slot = atomicAdd(&counters[7], 1);       // on to the longer series
 			atomicAdd(&counters[6], 1);
@@ -607,10 +616,8 @@ __device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int
 	}
 	double pval;
 	bool converged = true;
-	if (s1.converged && s2.converged) {
-		const double p1 = lugannani_rice(s1.root, s1.Kcur, s1.K2cur, qtilde, NAmu, NAsigma);
-		const double p2 = lugannani_rice(s2.root, s2.Kcur, s2.K2cur, qinv, NAmu, NAsigma);
-		pval = fabs(p1) + fabs(p2);
+	if ((st_mine & 2) && (st_other & 2)) {
+		pval = fabs(p_mine) + fabs(p_other);
 		if (pval != 0 && pn_in / pval > 1000) pval = pn_in;   // SPATest.cpp:368-371
 	} else {
 		pval = pn_in;
