@@ -150,6 +150,23 @@ __host__ __device__ constexpr size_t spa4_lds_bytes(int K)
 // of them), tier B from slot btop - 1 downwards (counters[7]); rec index of the v-th of a tier:
 __device__ __forceinline__ int spa4_rec(int tier, int btop, int v) { return tier ? btop - 1 - v : v; }
 
+// The segment's table rows -> LDS: whole KiB pieces by LDS-DMA (no round trip through registers, all of a
+// wave's pieces in flight at once), the tail of the last segment by ordinary copies.  The barrier that
+// follows in the callers (__syncthreads) drains the DMA.
+template <int NWAVES>
+__device__ __forceinline__ void spa4_stage_table(double *tab, const double *src, int ndouble)
+{
+	const int tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
+	const int npiece = (ndouble * 8) / 1024;
+	const uint8_t *s8 = reinterpret_cast<const uint8_t *>(src);
+	uint8_t *d8 = reinterpret_cast<uint8_t *>(tab);
+	for (int k = wid; k < npiece; k += NWAVES)
+		__builtin_amdgcn_global_load_lds(
+			(const __attribute__((address_space(1))) void *)(s8 + (size_t)k * 1024 + lane * 16),
+			(__attribute__((address_space(3))) void *)(d8 + k * 1024), 16, 0, 0);
+	for (int i = npiece * 128 + tid; i < ndouble; i += WAVE * NWAVES) tab[i] = src[i];
+}
+
 // The last workgroup to leave a moments kernel puts the item queue back to zero for the next launch on the
 // stream: cursor[0] = next item, cursor[1] = workgroups that are through.
 __device__ __forceinline__ void spa4_queue_done(int *cursor)
@@ -212,9 +229,7 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 		if (sg != seg) {
 			seg = sg;
 			const int rows = min(SEG, N - seg * SEG);
-			const double2 *src = reinterpret_cast<const double2 *>(md.XM + (size_t)seg * SEG * KP);
-			double2 *dst = reinterpret_cast<double2 *>(tab);
-			for (int i = tid; i < rows * (KP / 2); i += WAVE * spa4_waves(K)) dst[i] = src[i];
+			spa4_stage_table<spa4_waves(K)>(tab, md.XM + (size_t)seg * SEG * KP, rows * KP);
 			row_off = ((size_t)seg * (SEG / 16) + (size_t)lane * LDW) * 4;
 			mine = lane < NLANE && row_off + 4 * LDW <= bpv;
 			samp0 = seg * SEG + lane * LDW * 16;
@@ -398,9 +413,7 @@ spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, in
 		if (sg != seg) {
 			seg = sg;
 			const int nrow = min(SEG, N - seg * SEG);
-			const double2 *src = reinterpret_cast<const double2 *>(md.XM + (size_t)seg * SEG * KP);
-			double2 *dst = reinterpret_cast<double2 *>(tab);
-			for (int i = tid; i < nrow * (KP / 2); i += WAVE * spa4_waves(K)) dst[i] = src[i];
+			spa4_stage_table<spa4_waves(K)>(tab, md.XM + (size_t)seg * SEG * KP, nrow * KP);
 		}
 		for (int i = tid; i < nv; i += WAVE * spa4_waves(K)) {
 			const SpaRec &r = recs[spa4_rec(tier, btop, v0 + vb + i)];
