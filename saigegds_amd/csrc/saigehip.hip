@@ -797,6 +797,8 @@ static int sync_lane(sgx_handle *h)
 		h->stats.n_spa_dense = (uint64_t)h->h_counters[2];
 		h->stats.n_spa_slow = (uint64_t)h->h_counters[4];
 #ifdef SPA5_PROF
+		fprintf(stderr, "routing: tier A %d, tier B %d (of them handed on by A: %d), per-variant kernels %d (series list %d, exact list %d), dense %d\n",
+			h->h_counters[0], h->h_counters[7], h->h_counters[6], h->h_counters[5], h->h_counters[3], h->h_counters[4], h->h_counters[2]);
 		fprintf(stderr, "spa5 phases (10 ns ticks summed over variants): series kernel %d variants: stage %d count %d index %d gather %d series %d (sweep %d sum %d solve %d) | exact kernel %d variants: stage %d count %d index %d gather %d - sweeps %d\n",
 			h->h_counters[3], h->h_counters[8], h->h_counters[9], h->h_counters[10], h->h_counters[11], h->h_counters[12], h->h_counters[13], h->h_counters[14], h->h_counters[15],
 			h->h_counters[4], h->h_counters[16], h->h_counters[17], h->h_counters[18], h->h_counters[19], h->h_counters[21]);
