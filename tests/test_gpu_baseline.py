@@ -91,6 +91,39 @@ def test_baseline_c3_exact_path_agrees():
     np.testing.assert_allclose(a[v][:, 3:7], b[v][:, 3:7], rtol=1e-11)
 
 
+def test_baseline_c3_real_dosages():
+    """Real-valued dosage rows (the REAL branch of get_ds, saige_main.cpp:180-183) at N = 430 000: the tiled
+    one-pass score kernels and the dense form of the cumulant pass at the size of the benchmark (105
+    segments, items off the queue), against the oracle with the 1e-10 rule."""
+    from oracle import Oracle
+    from saigegds_amd.gds import unpack_dosage_2bit
+    n, m = 430_000, 320
+    sm, sc, packed, bpv = _baseline_case(n, "binary", 0.01, m)
+    try:
+        ds = unpack_dosage_2bit(packed.cpu().numpy()[:, :(n + 3) // 4], n)
+        dsf = ds.astype(np.float64)
+        dsf[ds == 0xFF] = np.nan
+        dsf[::2] *= 0.93                       # real-valued rows: AF/mac no longer integers
+        out, valid = sc.scan_f64(dsf)
+        tot, _ = sc.stats_total(reset=True)
+    finally:
+        sc.close()
+    ref, ref_valid = Oracle(sm).scan_f64(dsf)
+    assert np.array_equal(valid, ref_valid)
+    v = ref_valid.astype(bool)
+    # AF, mac, num differ by summation order only.  The reference adds the 430 000 doubles of a row one after
+    # the other (vectorization.cpp:186-205): ~1e-10 of rounding at this N, which the oracle reproduces; the
+    # device sums pairwise and sits at 1e-13 of the long-double sums.
+    np.testing.assert_allclose(out[v][:, :3], ref[v][:, :3], rtol=1e-9)
+    ac = np.nansum(dsf.astype(np.longdouble), axis=1)
+    num = np.sum(~np.isnan(dsf), axis=1)
+    np.testing.assert_allclose(out[v][:, 0], (ac / (2 * num)).astype(np.float64)[v], rtol=1e-13)
+    o2 = out.copy()
+    o2[:, :3] = ref[:, :3]
+    assert_table_close(o2, valid, ref, ref_valid, what="C3 real dosages")
+    assert tot["n_spa"] > 5, tot
+
+
 def test_grm_crossprod_at_430k():
     """Config 5's operator at full sample count: sgx_grm_crossprod over 320 markers vs grm_oracle.c."""
     from oracle import GrmOracle
