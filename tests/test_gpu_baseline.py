@@ -91,6 +91,40 @@ def test_baseline_c3_exact_path_agrees():
     np.testing.assert_allclose(a[v][:, 3:7], b[v][:, 3:7], rtol=1e-11)
 
 
+def test_baseline_c3_thirteen_covariates():
+    """K = 13 at N = 430 000: three column groups through the score kernel, 1024-sample segments and the
+    8-wave form of the cumulant pass (420 segments), against the oracle."""
+    from oracle import Oracle
+    sm, sc, packed, bpv = _baseline_case(430_000, "binary", 0.01, 800, k=13)
+    try:
+        out, valid, tot = _scan_two_lanes(sc, packed, bpv)
+        limbs, ngroups = sc.score_layout()
+    finally:
+        sc.close()
+    assert ngroups >= 3, (limbs, ngroups)
+    ref, ref_valid = Oracle(sm).scan_2bit(packed.cpu().numpy())
+    assert_table_close(out, valid, ref, ref_valid, what="C3 K=13")
+    assert tot["n_spa"] > 20, tot
+
+
+def test_baseline_c3_hard_call_bytes():
+    """RAW hard calls (0/1/2/0xFF) at N = 430 000: packed on the device and scanned by the MFMA path, so
+    the table is the 2-bit scan's, bit for bit."""
+    from saigegds_amd.gds import unpack_dosage_2bit
+    n, m = 430_000, 1000
+    sm, sc, packed, bpv = _baseline_case(n, "binary", 0.01, m)
+    try:
+        a, va, _ = _scan_two_lanes(sc, packed, bpv, 1)
+        ds = unpack_dosage_2bit(packed.cpu().numpy()[:, :(n + 3) // 4], n)
+        ds[ds == 3] = 0xFF                       # code 3 of the packed rows = missing = RAW 0xFF
+        b, vb = sc.scan_u8(ds)
+    finally:
+        sc.close()
+    assert np.array_equal(va, vb)
+    v = va.astype(bool)
+    assert np.array_equal(a[v], b[v])
+
+
 def test_baseline_c3_real_dosages():
     """Real-valued dosage rows (the REAL branch of get_ds, saige_main.cpp:180-183) at N = 430 000: the tiled
     one-pass score kernels and the dense form of the cumulant pass at the size of the benchmark (105
@@ -102,7 +136,7 @@ def test_baseline_c3_real_dosages():
     try:
         ds = unpack_dosage_2bit(packed.cpu().numpy()[:, :(n + 3) // 4], n)
         dsf = ds.astype(np.float64)
-        dsf[ds == 0xFF] = np.nan
+        dsf[ds == 3] = np.nan                  # code 3 of the packed rows = missing
         dsf[::2] *= 0.93                       # real-valued rows: AF/mac no longer integers
         out, valid = sc.scan_f64(dsf)
         tot, _ = sc.stats_total(reset=True)
