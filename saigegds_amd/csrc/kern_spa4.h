@@ -536,7 +536,7 @@ __device__ __forceinline__ bool spa4_root(const Spa4Series<NC> &S, double xmax, 
 template <int K, int NC>
 __device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int tier, int btop, int v0, int vcap, int v, int lane,
 	SpaRec *__restrict__ recs, int *__restrict__ counters, const double *__restrict__ segpart,
-	int *__restrict__ fb_dense, int *__restrict__ fb_spa2, double *__restrict__ out8, int force_dense, int force_exact);
+	int *__restrict__ fb_dense, int *__restrict__ fb_exact, double *__restrict__ out8, int force_dense, int force_exact);
 
 // one wave per flagged variant of the tier's round [v0, v0 + vcap).  A tier-A variant whose series
 // is too short is handed to tier B (a copy of its record at the end of that range); from tier B it goes
@@ -544,7 +544,7 @@ __device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int
 template <int K, int NC>
 __global__ void __launch_bounds__(256)
 spa4_solve(DevModel md, int nseg, int tier, int btop, int v0, int vcap, SpaRec *__restrict__ recs, int *__restrict__ counters,
-	const double *__restrict__ segpart, int *__restrict__ fb_dense, int *__restrict__ fb_spa2,
+	const double *__restrict__ segpart, int *__restrict__ fb_dense, int *__restrict__ fb_exact,
 	double *__restrict__ out8, int force_dense, int force_exact)
 {
 	// one wave per variant: the lanes share the segments' partial sums (fixed tree), then all of
@@ -552,14 +552,14 @@ spa4_solve(DevModel md, int nseg, int tier, int btop, int v0, int vcap, SpaRec *
 	const int lane = threadIdx.x & (WAVE - 1);
 	const int nflag = min(counters[tier ? 7 : 0] - v0, vcap);
 	for (int v = (blockIdx.x * blockDim.x + threadIdx.x) / WAVE; v < nflag; v += gridDim.x * blockDim.x / WAVE)
-		spa4_solve_one<K, NC>(md, nseg, tier, btop, v0, vcap, v, lane, recs, counters, segpart, fb_dense, fb_spa2, out8,
+		spa4_solve_one<K, NC>(md, nseg, tier, btop, v0, vcap, v, lane, recs, counters, segpart, fb_dense, fb_exact, out8,
 			force_dense, force_exact);
 }
 
 template <int K, int NC>
 __device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int tier, int btop, int v0, int vcap, int v, int lane,
 	SpaRec *__restrict__ recs, int *__restrict__ counters, const double *__restrict__ segpart,
-	int *__restrict__ fb_dense, int *__restrict__ fb_spa2, double *__restrict__ out8, int force_dense, int force_exact)
+	int *__restrict__ fb_dense, int *__restrict__ fb_exact, double *__restrict__ out8, int force_dense, int force_exact)
 {
 	constexpr int NS = NC + 5;
 	const int ri = spa4_rec(tier, btop, v0 + v);
@@ -623,7 +623,7 @@ __device__ __forceinline__ void spa4_solve_one(const DevModel &md, int nseg, int
 			atomicAdd(&counters[6], 1);
 			recs[btop - 1 - slot] = r;
 		} else {
-			fb_spa2[atomicAdd(&counters[3], 1)] = ri;
+			fb_exact[atomicAdd(&counters[4], 1)] = ri;      // the exact list (the per-variant series is this same series)
 		}
 		return;
 	}

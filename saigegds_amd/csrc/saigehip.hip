@@ -674,7 +674,7 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 				h->nseg, TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->cur5 + 2);  \
 		hipLaunchKernelGGL((spa4_solve<KK, NCX>), gsolve, dim3(256), 0, st, md, h->nseg, TIER,   \
 			btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->fallback,         \
-			h->fb_spa2, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0);                   \
+			h->fb_x2, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0);                     \
 	} while (0)
 #define CASE(KK)                                                                             \
 	case KK:                                                                                 \
