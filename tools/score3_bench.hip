@@ -1,0 +1,245 @@
+// tools/score3_bench.hip -- validation and timing of score3_kernel (saigegds_amd/csrc/kern_score3.h) alone.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -o tools/score3_bench tools/score3_bench.hip
+//   ./tools/score3_bench check            small shapes against a CPU sum (every instantiation below)
+//   ./tools/score3_bench [N=430000] [M=50000] [reps=5]
+// Inputs are random tiled blocks (codes 0/1/2, 1e-3 missing) and random limb tiles: the kernel's time does
+// not depend on the values.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+
+#define S3_KERNEL_ONLY
+#include "../saigegds_amd/csrc/kern_score3.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+static uint64_t sm64(uint64_t &x) { x += 0x9E3779B97F4A7C15ull; uint64_t z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
+
+__global__ void fill_codes(uint32_t *dst, size_t ndw, uint64_t seed)
+{
+	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < ndw; i += (size_t)gridDim.x * blockDim.x) {
+		uint64_t x = seed + i * 0x9E3779B97F4A7C15ull;
+		uint32_t w = 0;
+		for (int s = 0; s < 16; s++) {
+			x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+			const uint32_t u = (uint32_t)(x >> 40) & 0xFFFF;       // 16-bit uniform
+			const uint32_t code = u < 66 ? 3u : (u < 50000 ? 0u : (u < 62000 ? 1u : 2u));
+			w |= code << (2 * s);
+		}
+		dst[i] = w;
+	}
+}
+
+struct Shape { int N; size_t M; };
+
+template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int ABL>
+static float run(const char *name, const uint8_t *A, const uint8_t *Fl, int ntile, size_t M, int wg_per_cu, int n_cu, int *out, size_t out_ints,
+	int reps, S3Plan *plan_out = nullptr)
+{
+	const int grid = n_cu * wg_per_cu;
+	const S3Plan pl = s3_plan(M, ntile, grid, NAF * WAVES);
+	const size_t need = (size_t)pl.ng * pl.ipg * WAVES * NAF * NBF * 256;
+	if (need > out_ints) { fprintf(stderr, "%s: out buffer too small (%zu > %zu)\n", name, need, out_ints); exit(1); }
+	if (plan_out) *plan_out = pl;
+	const size_t lds = ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * WAVES * NAF) * 1024;
+	auto kern = score3_kernel<NBF, NAF, WAVES, NLA, NLB, DA, DB, ABL>;
+	static unsigned long long *stamps = nullptr;
+	if (!stamps) CK(hipMalloc((void **)&stamps, 16 * 4096));
+	CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipEvent_t a, b;
+	CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+	float best = 1e30f;
+	for (int rr = 0; rr < reps + 1; rr++) {
+		CK(hipEventRecord(a, 0));
+		hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * (WAVES + NLA + NLB)), lds, 0, A, Fl, pl, out, stamps);
+		CK(hipEventRecord(b, 0));
+		CK(hipEventSynchronize(b));
+		CK(hipGetLastError());
+		float ms = 0;
+		CK(hipEventElapsedTime(&ms, a, b));
+		if (rr > 0 || reps == 0) best = std::min(best, ms);
+	}
+	CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+	if (reps > 0) {
+		const double bytes = (double)M * (ntile * 64.0);
+		double ghz = 0;
+		if (ABL & 16) {
+			std::vector<unsigned long long> hs(2 * grid);
+			CK(hipMemcpy(hs.data(), stamps, hs.size() * 8, hipMemcpyDeviceToHost));
+			std::vector<double> c;
+			for (int b2 = 0; b2 < grid; b2++) if (hs[2 * b2 + 1]) c.push_back((double)hs[2 * b2] / (double)hs[2 * b2 + 1] * 0.1);
+			std::sort(c.begin(), c.end());
+			if (!c.empty()) ghz = c[c.size() / 2];
+		}
+		printf("%-40s NBF=%2d NAF=%d NC=%d NL=%d+%d D=%d/%d ABL=%2d  items/grp=%4d f=%2d  %7.3f ms  %6.0f GB/s  %.3f of 8 TB/s",
+			name, NBF, NAF, WAVES, NLA, NLB, DA, DB, ABL, pl.ipg, pl.f, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0);
+		if (ABL & 16) printf("  clock %.3f GHz", ghz);
+		printf("\n");
+		fflush(stdout);
+	}
+	return best;
+}
+
+// CPU check: sums of the item slabs per (variant, column) against the direct sum
+template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB>
+static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu)
+{
+	const int ntile = 2 * ((N + 511) / 512);
+	const size_t nfrag = (M + 15) / 16, abytes = nfrag * (size_t)ntile * 1024;
+	const int NCOL = 16 * NBF;
+	const size_t flbytes = (size_t)ntile * 16 * NCOL * 16;
+	std::vector<uint8_t> hA(abytes), hF(flbytes);
+	uint64_t x = 77 + N + M;
+	for (auto &v : hF) v = (uint8_t)sm64(x);
+	// codes: variant v, sample s
+	std::vector<uint8_t> code((size_t)nfrag * 16 * ((size_t)ntile * 256), 0);
+	for (size_t v = 0; v < nfrag * 16; v++)
+		for (size_t s = 0; s < (size_t)ntile * 256; s++) {
+			const uint32_t u = (uint32_t)(sm64(x) & 0xFFFF);
+			code[v * ntile * 256 + s] = (v < M && s < (size_t)N) ? (u < 300 ? 3 : (u < 40000 ? 0 : (u < 56000 ? 1 : 2))) : (uint8_t)(sm64(x) & 3);   // padding holds garbage codes
+		}
+	// padding samples (>= N) must see zero limbs, as sgx_init writes them
+	for (int t = 0; t < ntile; t++)
+		for (int g16 = 0; g16 < 16; g16++)
+			for (int e = 0; e < 16; e++) {
+				const size_t s = (size_t)t * 256 + g16 * 16 + e;
+				if (s >= (size_t)N)
+					for (int c = 0; c < NCOL; c++) hF[((size_t)(t * 16 + g16) * NCOL + c) * 16 + s3_pos(e)] = 0;
+			}
+	for (size_t v = 0; v < nfrag * 16; v++)
+		for (size_t p = 0; p < (size_t)ntile * 4; p++) {
+			uint32_t w[4] = {0, 0, 0, 0};
+			for (int u = 0; u < 4; u++)
+				for (int e = 0; e < 16; e++) w[u] |= (uint32_t)code[v * ntile * 256 + p * 64 + u * 16 + e] << (2 * e);
+			memcpy(&hA[s3_piece_off(v, p, ntile)], w, 16);
+		}
+	uint8_t *dA, *dF; int *dO;
+	CK(hipMalloc((void **)&dA, abytes)); CK(hipMalloc((void **)&dF, flbytes));
+	CK(hipMemcpy(dA, hA.data(), abytes, hipMemcpyHostToDevice));
+	CK(hipMemcpy(dF, hF.data(), flbytes, hipMemcpyHostToDevice));
+	const int grid = n_cu * wg_per_cu;
+	const S3Plan pl0 = s3_plan(M, ntile, grid, NAF * WAVES);
+	const size_t oints = (size_t)pl0.ng * pl0.ipg * WAVES * NAF * NBF * 256;
+	CK(hipMalloc((void **)&dO, oints * 4));
+	CK(hipMemset(dO, 0xCD, oints * 4));
+	S3Plan pl;
+	run<NBF, NAF, WAVES, NLA, NLB, DA, DB, 0>(name, dA, dF, ntile, M, wg_per_cu, n_cu, dO, oints, 0, &pl);
+	std::vector<int> hO(oints);
+	CK(hipMemcpy(hO.data(), dO, oints * 4, hipMemcpyDeviceToHost));
+	long long bad = 0;
+	for (size_t v = 0; v < M; v++) {
+		const int vtile = (int)(v / (16 * (size_t)pl.fpw)), within = (int)(v % (16 * (size_t)pl.fpw));
+		const int wid = within / (16 * NAF), f = (within / 16) % NAF, row = within % 16, kg = row / 4, reg = row % 4;
+		for (int c = 0; c < NCOL; c++) {
+			long long ref = 0;
+			for (size_t s = 0; s < (size_t)ntile * 256; s++) {
+				const int cd = code[v * ntile * 256 + s];
+				const int t = (int)(s / 256), g16 = (int)(s % 256) / 16, e = (int)(s % 16);
+				const int a = ((c >= NCOL - 16) ? (cd & 2) : cd) * s3_scale(e);
+				ref += (long long)a * (int8_t)hF[((size_t)(t * 16 + g16) * NCOL + c) * 16 + s3_pos(e)];
+			}
+			long long got = 0;
+			for (int g = 0; g < pl.ng; g++) {
+				int first, count;
+				s3_items_of(pl, vtile, g, first, count);
+				for (int id = first; id < first + count; id++)
+					got += hO[(((size_t)id * WAVES + wid) * NAF + f) * NBF * 256 + (size_t)(c / 16) * 256 + reg * 64 + kg * 16 + (c % 16)];
+			}
+			if (got != ref) { if (bad < 5) fprintf(stderr, "%s: variant %zu col %d: got %lld want %lld\n", name, v, c, got, ref); bad++; }
+		}
+	}
+	printf("check %-30s N=%d M=%zu ntile=%d ng=%d wpg=%d rf=%d rem=%d f=%d: %s\n", name, N, M, ntile, pl.ng, pl.wpg, pl.rf, pl.rem, pl.f, bad ? "FAILED" : "ok");
+	CK(hipFree(dA)); CK(hipFree(dF)); CK(hipFree(dO));
+	return bad ? 1 : 0;
+}
+
+int main(int argc, char **argv)
+{
+	hipDeviceProp_t pr; CK(hipGetDeviceProperties(&pr, 0));
+	const int n_cu = pr.multiProcessorCount;
+	if (argc > 1 && !strcmp(argv[1], "check")) {
+		int bad = 0;
+		// grids far smaller than the chip so that rounds, leftovers and pieces all occur
+		bad += check<4, 4, 8, 3, 1, 2, 2>("k3 naf4 d2", 5000, 700, 1, 8);
+		bad += check<4, 4, 8, 3, 1, 3, 1>("k3 naf4 big grid", 3000, 300, 1, n_cu);
+		bad += check<4, 3, 8, 3, 1, 4, 1>("k3 naf3 d4/1", 4100, 1000, 1, 16);
+		bad += check<4, 6, 4, 3, 1, 4, 1>("k3 naf6 4+3+1", 4100, 1000, 1, 16);
+		bad += check<4, 4, 4, 1, 1, 1, 1>("k3 naf4 d1", 1000, 130, 1, 8);
+		bad += check<4, 4, 8, 2, 2, 2, 2>("k3 naf4 tiny N", 100, 50, 1, 8);
+		bad += check<4, 2, 12, 3, 1, 4, 2>("k3 naf2 12 waves", 9000, 2100, 1, 8);
+		bad += check<11, 4, 4, 3, 1, 3, 1>("k13 naf4 4+3+1", 2500, 800, 1, 8);
+		bad += check<6, 3, 8, 3, 1, 3, 1>("k5 naf3", 2100, 900, 1, 8);
+		bad += check<2, 4, 8, 3, 1, 3, 2>("quant naf4", 2100, 900, 1, 8);
+		bad += check<13, 3, 4, 2, 2, 3, 1>("k16 naf3 4+2+2", 1500, 500, 1, 8);
+		bad += check<8, 4, 4, 3, 1, 3, 1>("k8 naf4 4+3+1", 1500, 500, 1, 8);
+		return bad ? 1 : 0;
+	}
+	const int N = argc > 1 ? atoi(argv[1]) : 430000;
+	const size_t M = argc > 2 ? (size_t)atoll(argv[2]) : 50000;
+	const int reps = argc > 3 ? atoi(argv[3]) : 5;
+	const int ntile = 2 * ((N + 511) / 512);
+	const size_t abytes = s3_block_bytes(M, ntile);
+	uint8_t *A, *Fl; int *out;
+	CK(hipMalloc((void **)&A, abytes));
+	fill_codes<<<4096, 256>>>((uint32_t *)A, abytes / 4, 12345);
+	if (getenv("ZERO_A")) CK(hipMemset(A, 0, abytes));
+	const int NBFMAX = 13;
+	const size_t flb = (size_t)ntile * 16 * 16 * NBFMAX * 16;
+	CK(hipMalloc((void **)&Fl, flb));
+	{ std::vector<uint8_t> hf(flb); uint64_t x = 5; for (auto &v : hf) v = getenv("ZERO_B") ? 0 : (uint8_t)sm64(x); CK(hipMemcpy(Fl, hf.data(), flb, hipMemcpyHostToDevice)); }
+	const size_t oints = (size_t)1 << 30;       // 4 GiB of slabs: enough for every variant below
+	CK(hipMalloc((void **)&out, oints * 4));
+	CK(hipDeviceSynchronize());
+	printf("N=%d M=%zu ntile=%d rows %.3f GB, %d CUs\n", N, M, ntile, (double)M * ntile * 64 / 1e9, n_cu);
+#define R(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, name) do { \
+	const size_t lds_ = ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * NC * NAF) * 1024; \
+	if (lds_ > 163840) { printf("%-40s skipped: %zu B of LDS\n", name, lds_); break; } \
+	run<NBF, NAF, NC, NLA, NLB, DA, DB, ABL>(name, A, Fl, ntile, M, 1, n_cu, out, oints, reps); } while (0)
+	// K = 3 (3 value fragments + bit-1)
+	if (getenv("SHORT")) {
+		R(4, 4, 8, 3, 1, 2, 2, 16, "k3 naf4 8+3+1 d2/2");
+		R(4, 3, 8, 2, 2, 4, 1, 16, "k3 naf3 8+2+2 d4/1");
+		R(4, 6, 4, 3, 1, 4, 1, 16, "k3 naf6 4+3+1 d4/1");
+		R(4, 6, 4, 2, 2, 4, 1, 16, "k3 naf6 4+2+2 d4/1");
+		R(4, 4, 8, 3, 1, 3, 1, 6 | 16, "k3 naf4 no DMA");
+		R(4, 6, 4, 3, 1, 4, 1, 6 | 16, "k3 naf6 no DMA");
+		R(4, 4, 8, 3, 1, 3, 1, 1 | 16, "k3 naf4 memory system only");
+		R(2, 4, 8, 3, 1, 3, 2, 16, "quant naf4 8+3+1 d3/2");
+		R(11, 4, 4, 2, 2, 3, 1, 16, "k13 naf4 4+2+2 d3/1");
+		return 0;
+	}
+	R(4, 4, 8, 3, 1, 2, 2, 16, "k3 naf4 8+3+1 d2/2");
+	R(4, 4, 8, 3, 1, 3, 1, 16, "k3 naf4 8+3+1 d3/1");
+	R(4, 4, 8, 4, 0 + 1, 3, 1, 0, "k3 naf4 8+4+1 d3/1");
+	R(4, 3, 8, 3, 1, 4, 1, 16, "k3 naf3 8+3+1 d4/1");
+	R(4, 3, 8, 3, 1, 3, 2, 0, "k3 naf3 8+3+1 d3/2");
+	R(4, 3, 8, 3, 1, 4, 2, 0, "k3 naf3 8+3+1 d4/2");
+	R(4, 3, 8, 6, 2, 4, 1, 0, "k3 naf3 8+6+2 d4/1");
+	R(4, 3, 8, 2, 2, 4, 1, 0, "k3 naf3 8+2+2 d4/1");
+	R(4, 2, 12, 3, 1, 4, 1, 16, "k3 naf2 12+3+1 d4/1");
+	R(4, 2, 12, 3, 1, 4, 2, 0, "k3 naf2 12+3+1 d4/2");
+	R(4, 2, 8, 3, 1, 6, 2, 0, "k3 naf2 8+3+1 d6/2");
+	R(4, 4, 8, 3, 1, 3, 1, 1 | 16, "k3 naf4 memory system only");
+	R(4, 4, 8, 3, 1, 3, 1, 6 | 16, "k3 naf4 no DMA");
+	R(4, 3, 8, 3, 1, 4, 1, 1 | 16, "k3 naf3 memory system only");
+	R(4, 3, 8, 3, 1, 4, 1, 6 | 16, "k3 naf3 no DMA");
+	R(4, 3, 8, 3, 1, 4, 1, 2 | 16, "k3 naf3 no row DMA");
+	// quantitative (value fragment + bit-1: 2 fragments)
+	R(2, 4, 8, 3, 1, 3, 2, 0, "quant naf4 8+3+1 d3/2");
+	R(2, 4, 8, 3, 1, 4, 1, 0, "quant naf4 8+3+1 d4/1");
+	// K = 5, 8, 13, 16
+	R(6, 3, 8, 3, 1, 3, 1, 0, "k5 naf3 8+3+1 d3/1");
+	R(6, 3, 8, 2, 2, 3, 1, 0, "k5 naf3 8+2+2 d3/1");
+	R(8, 4, 4, 3, 1, 3, 1, 0, "k8 naf4 4+3+1 d3/1");
+	R(8, 4, 4, 2, 2, 3, 1, 0, "k8 naf4 4+2+2 d3/1");
+	R(11, 4, 4, 2, 2, 3, 1, 16, "k13 naf4 4+2+2 d3/1");
+	R(11, 4, 4, 3, 1, 3, 1, 0, "k13 naf4 4+3+1 d3/1");
+	R(11, 4, 4, 2, 2, 3, 1, 6 | 16, "k13 naf4 no DMA");
+	R(13, 3, 4, 2, 2, 3, 1, 0, "k16 naf3 4+2+2 d3/1");
+	// N = 50 000 shape is run by passing N on the command line
+	return 0;
+}
