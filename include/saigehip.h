@@ -141,6 +141,34 @@ int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev,
 	size_t bytes_per_variant, size_t n_variants, double *out8_dev,
 	uint8_t *valid_dev);
 
+/* Genotype blocks: the library's device layout of 2-bit rows -----------------------------------
+ * The reference streams one variant at a time out of the GDS file into its C++ code
+ * (R/assoc_single.r:202-209, seqApply).  Here the unit that is brought into HBM and scanned is a
+ * BLOCK of variants: on load the rows are rearranged on the device into tiles of 16 variants x 256
+ * samples (one contiguous KiB each: what a wavefront of the score kernel reads with one instruction)
+ * and the positions of the missing genotypes are listed per variant.  A block depends on the number
+ * of samples only, so one loaded block can be scanned with any number of models (phenotypes).
+ * sgx_scan_2bit / sgx_scan_2bit_dev are this load followed by sgx_scan_block on a scratch block.
+ *   sgx_block_create    device storage for up to max_variants rows of n_samp samples
+ *   sgx_block_bytes     what that takes (rows + lists: about 1.13 x the packed rows at large N)
+ *   sgx_block_load_dev  rows already in this GPU's memory (bytes_per_variant a multiple of 16,
+ *                       >= sgx_row_stride(n_samp), 16-byte aligned); asynchronous on the handle's stream
+ *   sgx_block_load      rows in host memory (>= ceil(n_samp / 4) bytes each), through the pinned pipeline
+ *   sgx_scan_block      the scan; asynchronous like sgx_scan_2bit_dev (same lanes, stats, sgx_sync)
+ * Variants with more missing genotypes than the block's lists hold (a list entry per missing
+ * genotype, room for 0.8 % of the block at large N) are scanned by the FP64 kernels instead: same
+ * results, slower. */
+typedef struct sgx_block sgx_block;
+size_t sgx_block_bytes(int32_t n_samp, size_t max_variants);
+int  sgx_block_create(int32_t n_samp, size_t max_variants, int device, sgx_block **out);
+void sgx_block_free(sgx_block *b);
+int  sgx_block_load_dev(sgx_handle *h, sgx_block *b, const uint8_t *packed_dev,
+	size_t bytes_per_variant, size_t n_variants);
+int  sgx_block_load(sgx_handle *h, sgx_block *b, const uint8_t *packed,
+	size_t bytes_per_variant, size_t n_variants);
+size_t sgx_block_variants(const sgx_block *b);
+int  sgx_scan_block(sgx_handle *h, const sgx_block *b, double *out8_dev, uint8_t *valid_dev);
+
 /* Dosage inputs in HOST memory, one row of N values per variant, the three branches of get_ds
  * (src/saige_main.cpp:171-183):
  *   u8 : 0..254, 0xFF = missing (RAWSXP :179-182);  i32: NA_INTEGER (INT_MIN) = missing (INTSXP

@@ -16,6 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libsaigehip.so")
 EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
     "sgx_set_thresholds", "sgx_score_layout", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_i32", "sgx_scan_f64", "sgx_host_alloc", "sgx_host_free", "sgx_burden_2bit", "sgx_geno_stats_2bit",
+    "sgx_block_bytes", "sgx_block_create", "sgx_block_free", "sgx_block_load_dev", "sgx_block_load", "sgx_block_variants", "sgx_scan_block",
     "sgx_sync", "sgx_get_stats", "sgx_get_stats_total", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
     "sgx_grm_init", "sgx_grm_init_dev", "sgx_grm_crossprod_dev", "sgx_grm_sync", "sgx_grm_free", "sgx_grm_diag", "sgx_grm_crossprod", "sgx_grm_pcg",
 )
@@ -101,6 +102,20 @@ def load():
     L.sgx_scan_2bit.argtypes = [vp, vp, sz, sz, vp, vp]
     L.sgx_scan_2bit_dev.restype = C.c_int
     L.sgx_scan_2bit_dev.argtypes = [vp, vp, sz, sz, vp, vp]
+    L.sgx_block_bytes.restype = sz
+    L.sgx_block_bytes.argtypes = [C.c_int32, sz]
+    L.sgx_block_create.restype = C.c_int
+    L.sgx_block_create.argtypes = [C.c_int32, sz, C.c_int, C.POINTER(vp)]
+    L.sgx_block_free.restype = None
+    L.sgx_block_free.argtypes = [vp]
+    L.sgx_block_load_dev.restype = C.c_int
+    L.sgx_block_load_dev.argtypes = [vp, vp, vp, sz, sz]
+    L.sgx_block_load.restype = C.c_int
+    L.sgx_block_load.argtypes = [vp, vp, vp, sz, sz]
+    L.sgx_block_variants.restype = sz
+    L.sgx_block_variants.argtypes = [vp]
+    L.sgx_scan_block.restype = C.c_int
+    L.sgx_scan_block.argtypes = [vp, vp, vp, vp]
     L.sgx_scan_u8.restype = C.c_int
     L.sgx_scan_u8.argtypes = [vp, vp, sz, vp, vp]
     L.sgx_scan_f64.restype = C.c_int
@@ -259,6 +274,22 @@ class Scanner:
     def scan_2bit_dev(self, packed_ptr: int, bpv: int, m: int, out_ptr: int, valid_ptr: int):
         check(self._L.sgx_scan_2bit_dev(self._h, packed_ptr, bpv, m, out_ptr, valid_ptr))
 
+    # -- genotype blocks (the library's tiled device layout; Block below) ---
+    def load_block_dev(self, block: "Block", packed_ptr: int, bpv: int, m: int):
+        """Rows already in this GPU's memory -> block (asynchronous on the handle's stream)."""
+        check(self._L.sgx_block_load_dev(self._h, block._b, packed_ptr, bpv, m))
+
+    def load_block(self, block: "Block", packed: np.ndarray):
+        """Rows in host memory -> block, through the pinned pipeline."""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        if packed.ndim != 2:
+            raise ValueError("packed genotypes must be [n_variants, bytes_per_variant]")
+        check(self._L.sgx_block_load(self._h, block._b, packed.ctypes.data, packed.shape[1], packed.shape[0]))
+
+    def scan_block(self, block: "Block", out_ptr: int, valid_ptr: int):
+        """Scan of a loaded block into device buffers (asynchronous; sync() before reading)."""
+        check(self._L.sgx_scan_block(self._h, block._b, out_ptr, valid_ptr))
+
     def synth_2bit_dev(self, packed_ptr: int, bpv: int, m: int, first_variant: int, seed: int,
                        thr_ptr: int):
         check(self._L.sgx_synth_2bit_dev(self._h, packed_ptr, bpv, self.n, m, first_variant, seed,
@@ -291,6 +322,43 @@ class Scanner:
 
     def set_thresholds(self, maf, mac, missing, spa_pval):
         check(self._L.sgx_set_thresholds(self._h, maf, mac, missing, spa_pval))
+
+
+class Block:
+    """A block of variants in the library's device layout (``sgx_block``): depends on the number of
+    samples only, so one loaded block can be scanned with any number of models."""
+
+    def __init__(self, n_samp: int, max_variants: int, device: int = 0):
+        self._L = load()
+        b = C.c_void_p()
+        check(self._L.sgx_block_create(int(n_samp), int(max_variants), int(device), C.byref(b)))
+        self._b = b
+        self.n, self.cap = int(n_samp), int(max_variants)
+
+    @staticmethod
+    def nbytes(n_samp: int, max_variants: int) -> int:
+        return int(load().sgx_block_bytes(int(n_samp), int(max_variants)))
+
+    @property
+    def n_variants(self) -> int:
+        return int(self._L.sgx_block_variants(self._b))
+
+    def close(self):
+        if getattr(self, "_b", None):
+            self._L.sgx_block_free(self._b)
+            self._b = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
 
 
 class PinnedBuffer:

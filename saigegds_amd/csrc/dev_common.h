@@ -1,6 +1,26 @@
 // dev_common.h -- device model, Rmath stand-ins, reductions, 2-bit helpers, score epilogue
 // Part of libsaigehip.so (single translation unit: saigehip.hip).
 #pragma once
+#include "s3_layout.h"
+
+// ---------------------------------------------------------------------------
+// Rows of a block of variants as the kernels see them: row-major (dosage rows, 2-bit rows of the FP64 test
+// hook) or the tiled layout of a genotype block (s3_layout.h).  Everything reads 2-bit rows in 16-byte pieces
+// (64 samples).
+struct RowsRef {
+	const uint8_t *base;
+	size_t bpv;       // row-major: bytes per row
+	int ntile;        // tiled: 256-sample tiles per row; 0 = row-major
+};
+// byte offset of piece p of row j
+__device__ __forceinline__ size_t rr_piece(const RowsRef &rr, size_t j, size_t p)
+{
+	return rr.ntile ? s3_piece_off(j, p, rr.ntile) : j * rr.bpv + p * 16;
+}
+// bytes of a 2-bit row that may be read
+__device__ __forceinline__ size_t rr_row_bytes(const RowsRef &rr) { return rr.ntile ? (size_t)rr.ntile * 64 : rr.bpv; }
+// start of row j of a row-major block (dosage rows)
+__device__ __forceinline__ const uint8_t *rr_row(const RowsRef &rr, size_t j) { return rr.base + j * rr.bpv; }
 
 // ---------------------------------------------------------------------------
 // device-side model

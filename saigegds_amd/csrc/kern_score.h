@@ -10,24 +10,27 @@
 
 template <int P, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
-score2b_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, DevModel md,
+score2b_kernel(RowsRef rr, int M, DevModel md,
 	SpaRec *__restrict__ recs, int *__restrict__ counters, double *__restrict__ out8,
-	uint8_t *__restrict__ valid)
+	uint8_t *__restrict__ valid, const int *__restrict__ list, int list_counter, int btop, int *__restrict__ fb_series, int *__restrict__ fb_exact)
 {
 	__shared__ double sh[P * (BLOCK / WAVE)];
 	__shared__ int shi[3 * (BLOCK / WAVE)];
-	const int j = blockIdx.x;
-	if (j >= M) return;
+	// list: the variants to take (counters[list_counter] of them, grid-stride); else variant = workgroup
+	const int nwork = list ? counters[list_counter] : M;
+	for (int wi = blockIdx.x; wi < nwork; wi += gridDim.x) {
+	const int j = list ? list[wi] : wi;
 	const int N = md.N, tid = threadIdx.x;
 	const int lane = tid & (WAVE - 1), wid = tid / WAVE;
 	constexpr int NW = BLOCK / WAVE;
-	const uint4 *row = reinterpret_cast<const uint4 *>(packed + (size_t)j * bpv);
 	const int nvec = (N + 63) >> 6;
+	auto row_piece = [&](int v) -> uint4 { return *reinterpret_cast<const uint4 *>(rr.base + rr_piece(rr, (size_t)j, (size_t)v)); };
+	__syncthreads();                     // the previous variant's readers of sh / shi are done
 
 	// ---- pass 1 ----
 	int n1 = 0, n2 = 0, n3 = 0;
 	for (int v = tid; v < nvec; v += BLOCK) {
-		const uint4 q = row[v];
+		const uint4 q = row_piece(v);
 		const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
 		for (int d = 0; d < 4; d++) {
@@ -48,7 +51,7 @@ score2b_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, DevModel m
 	const VarHead h = make_head(md, double(n1 + 2 * n2), N - n3);
 	if (!h.pass) {
 		if (tid == 0) { nan_row(out8 + (size_t)j * 8); valid[j] = 0; }
-		return;
+		continue;
 	}
 
 	// ---- pass 2 ----
@@ -58,7 +61,7 @@ score2b_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, DevModel m
 	const uint32_t zx = h.minus ? 0xAAAAAAAAu : 0u;   // xor that maps the zero-dosage code to 0
 	const double *__restrict__ F = md.F;
 	for (int v = tid; v < nvec; v += BLOCK) {
-		const uint4 q = row[v];
+		const uint4 q = row_piece(v);
 		const uint32_t ww[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
 		for (int d = 0; d < 4; d++) {
@@ -90,18 +93,11 @@ score2b_kernel(const uint8_t *__restrict__ packed, size_t bpv, int M, DevModel m
 		double cbuf[KMAX], pn, Ssc, v2sc;
 		valid[j] = 1;
 		if (score_epilogue<(P - 2) / 2>(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
-			const int slot = atomicAdd(&counters[0], 1);
-			SpaRec r;
-			r.j = j; r.minus = h.minus; r.AC2 = h.minus ? (2 * h.Num - h.AC) : h.AC;
-			r.nnz = h.minus ? (N - n2) : (n1 + n2 + n3); r.has_gmu = 0; r.sum_gmu = 0;
-			r.p_noadj = pn; r.S = Ssc; r.var2 = v2sc; r.tscale = spa_tscale(Ssc, v2sc, r.AC2, md.r);
-			for (int a = 0; a < 4; a++) r.lut[a] = h.lut[a];
-			
-#pragma unroll
-			for (int a = 0; a < KMAX; a++) r.c[a] = cbuf[a];
-			recs[slot] = r;
+			spa_push<(P - 2) / 2>(md, recs, counters, btop, fb_series, fb_exact, j, h.minus, h.minus ? (2 * h.Num - h.AC) : h.AC,
+				h.minus ? (N - n2) : (n1 + n2 + n3), h.lut, pn, Ssc, v2sc, cbuf);
 		}
 		atomicAdd(&counters[1], 1);
+	}
 	}
 }
 

@@ -25,67 +25,7 @@
 typedef int s3_v4i __attribute__((ext_vector_type(4)));
 #endif
 
-// ---- work decomposition (host-computed, by value) ------------------------------------------------
-// The grid has `grid` workgroups (a multiple of 8).  Workgroups with equal (blockIdx % 8) % ng share a
-// TILE GROUP g: a contiguous range of 256-sample tiles [g ntile / ng, (g + 1) ntile / ng), so that an
-// XCD (blocks are dealt round-robin over the 8 XCDs: a placement guess, never correctness) streams the
-// same B tiles from its L2.  Inside a group the wpg workgroups take the variant tiles round-robin: rf
-// full rounds, then the rem leftover variant tiles cut into f tile sub-ranges each so that the last
-// round is spread over (nearly) all workgroups.  Every item writes its own slab of partial sums.
-struct S3Plan {
-	int ntile;      // 256-sample tiles of a row
-	int nfrag;      // 16-variant fragments = ceil(M / 16)
-	int fpw;        // fragments per workgroup = NAF * WAVES of the instantiation
-	int vt;         // variant tiles = ceil(nfrag / fpw)
-	int ng;         // tile groups: 8, 4, 2 or 1
-	int wpg;        // workgroups per group = grid / ng
-	int rf;         // full rounds = vt / wpg
-	int rem;        // leftover variant tiles = vt % wpg
-	int f;          // pieces per leftover variant tile (0 if rem == 0)
-	int ipg;        // items per group = rf * wpg + rem * f
-};
-
-static inline S3Plan s3_plan(size_t M, int ntile, int grid, int fpw)
-{
-	S3Plan p{};
-	p.ntile = ntile;
-	p.nfrag = (int)((M + 15) / 16);
-	p.fpw = fpw;
-	p.vt = (p.nfrag + fpw - 1) / fpw;
-	p.ng = 8;
-	while (p.ng > 1 && ntile / p.ng < 8) p.ng >>= 1;
-	p.wpg = grid / p.ng;
-	p.rf = p.vt / p.wpg;
-	p.rem = p.vt % p.wpg;
-	p.f = 0;
-	if (p.rem) {
-		const int bylen = (ntile / p.ng) / 4 > 0 ? (ntile / p.ng) / 4 : 1;    // a piece is at least ~4 tiles
-		p.f = p.wpg / p.rem < bylen ? p.wpg / p.rem : bylen;
-		if (p.f < 1) p.f = 1;
-	}
-	p.ipg = p.rf * p.wpg + p.rem * p.f;
-	return p;
-}
-
-// items of variant tile `vtile` in group g: ids [first, first + count)
-__host__ __device__ __forceinline__ void s3_items_of(const S3Plan &p, int vtile, int g, int &first, int &count)
-{
-	if (vtile < p.rf * p.wpg) { first = g * p.ipg + vtile; count = 1; }
-	else { first = g * p.ipg + p.rf * p.wpg + (vtile - p.rf * p.wpg) * p.f; count = p.f; }
-}
-
-// bytes of one tiled block of M variants: nfrag fragments x ntile KiB
-static inline size_t s3_block_bytes(size_t M, int ntile) { return ((M + 15) / 16) * (size_t)ntile * 1024; }
-
-// byte offset of the 16-B piece p (64 samples) of variant j in the tiled layout
-__host__ __device__ __forceinline__ size_t s3_piece_off(size_t j, size_t p, int ntile)
-{
-	return ((j >> 4) * (size_t)ntile + (p >> 2)) * 1024 + (((p & 3) << 4) + (j & 15)) * 16;
-}
-
-// Sample order inside a group of 16 (as kern_score_mfma.h mf_pos): byte j of (w >> 2t) & 0x03030303 is
-// the code of sample 4 j + t, and the B tiles store the 16 samples of a group in that order.
-__host__ __device__ __forceinline__ int s3_pos(int s) { return ((s & 3) << 2) | (s >> 2); }
+#include "s3_layout.h"
 
 // LDS reads the compiler does not see as such (see the kernel), and the waits that go with them: the
 // wait is tied to the registers it covers so that no use is scheduled in front of it
@@ -129,14 +69,6 @@ __device__ __forceinline__ void s3_unpack_op(uint32_t w, uint32_t &w4, s3_v4i &v
 	else if constexpr (OP == 7) b1[2] = (int)(w4 & 0x02020202u);
 	else if constexpr (OP == 8) b1[3] = (int)(w4 & 0x08080808u);
 }
-#define S3_NOPS 9
-// scale of the code at position e (0..15) of a dword: byte e / 4 ... no: code e sits in bits 2e, 2e + 1, i.e.
-// byte e >> 2, position e & 3 of that byte
-__host__ __device__ __forceinline__ int s3_scale(int e) { return (e & 1) ? 4 : 1; }
-// byte of the A operand (and of a B tile's 16-byte group) that holds code e of a dword: operand dword t holds,
-// in byte j, the code of byte j of the packed dword at position t -> code e = 4 j + t sits at byte 4 t + j
-// (the same order as kern_score_mfma.h mf_pos)
-
 // NBF: B fragments per tile (value fragments + the bit-1 fragment, the LAST one).  NAF: A fragments (16
 // variants) per consumer wave.  NC consumer waves + NLA row-loader waves + NLB B-loader waves per workgroup
 // (one workgroup per CU).
@@ -390,3 +322,308 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 	}
 #endif
 }
+
+#ifndef S3_KERNEL_ONLY   /* tools/score3_bench.hip takes the contraction kernel alone */
+// ===========================================================================================================
+// Genotype blocks: ingest (row-major 2-bit rows -> tiled layout + lists of the missing genotypes), the sparse
+// T3 pass, the reduction of the item slabs and the epilogue.
+
+// ---- ingest 1: transpose to tiles, count the missing codes per (sample range, variant).
+// One wave per fragment of 16 variants; lane (r, kg) moves the 16 B of variant 16 frag + r that cover samples
+// 64 kg .. 64 kg + 63 of the tile.  Codes of samples >= N are cleared (a stray 3 there must not be listed).
+// rows: M rows of bpv bytes, bpv >= 64 ntile, 16-byte aligned.
+__global__ void __launch_bounds__(256)
+s3_ingest_tile_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int M, int ntile,
+	uint8_t *__restrict__ tiles, int *__restrict__ cnt, size_t cap)
+{
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	const int frag = blockIdx.x * 4 + wid, nfrag = (M + 15) / 16;
+	if (frag >= nfrag) return;
+	const int r = lane & 15, kg = lane >> 4, v = frag * 16 + r;
+	const bool live = v < M;
+	const uint8_t *src = rows + (size_t)(live ? v : 0) * bpv + kg * 16;
+	uint8_t *dst = tiles + (size_t)frag * ntile * 1024 + lane * 16;
+	constexpr int UN = 4;
+	int rg = 0, tend = s3_range_t0(1, ntile), c = 0;
+	for (int t0 = 0; t0 < ntile; t0 += UN) {
+		uint4 w[UN];
+#pragma unroll
+		for (int j = 0; j < UN; j++) {
+			w[j] = make_uint4(0u, 0u, 0u, 0u);
+			if (live && t0 + j < ntile) w[j] = *reinterpret_cast<const uint4 *>(src + (size_t)(t0 + j) * 64);
+		}
+#pragma unroll
+		for (int j = 0; j < UN; j++) {
+			const int t = t0 + j;
+			if (t >= ntile) break;
+			while (t >= tend) {         // the range is complete: its count per variant (the four kg lanes together)
+				int tot = c + __shfl_xor(c, 16, 64);
+				tot += __shfl_xor(tot, 32, 64);
+				if (kg == 0 && live) cnt[(size_t)rg * cap + v] = tot;
+				c = 0; rg++; tend = s3_range_t0(rg + 1, ntile);
+			}
+			const int s0 = t * 256 + kg * 64;
+			uint32_t d[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				const int keep = N - s0 - 16 * u;
+				d[u] &= (keep >= 16) ? 0xFFFFFFFFu : ((keep <= 0) ? 0u : ((1u << (2 * keep)) - 1u));
+				c += __popc(d[u] & (d[u] >> 1) & 0x55555555u);
+			}
+			*reinterpret_cast<uint4 *>(dst + (size_t)t * 1024) = make_uint4(d[0], d[1], d[2], d[3]);
+		}
+	}
+	while (rg < S3_NR) {
+		int tot = c + __shfl_xor(c, 16, 64);
+		tot += __shfl_xor(tot, 32, 64);
+		if (kg == 0 && live) cnt[(size_t)rg * cap + v] = tot;
+		c = 0; rg++;
+	}
+}
+
+// ---- ingest 2 (one workgroup of 1024): per variant n3 and the overflow mark, then the exclusive prefix of the
+// listed counts in (range, variant) order.  A variant whose missing genotypes exceed `lim`, or that no longer
+// fits the block's list, is marked (ovf = 1, counts zeroed): the scan takes it through the FP64 kernel.
+__global__ void __launch_bounds__(1024)
+s3_ingest_scan_kernel(int M, size_t cap, int lim, unsigned idx_cap, int *__restrict__ cnt, int *__restrict__ n3,
+	uint8_t *__restrict__ ovf, unsigned *__restrict__ ptr)
+{
+	__shared__ unsigned long long sh[1024];
+	__shared__ unsigned long long carry;
+	const int tid = threadIdx.x;
+	auto block_excl = [&](unsigned long long x) -> unsigned long long {       // exclusive prefix over the threads; sh[1023] + own of last = total
+		sh[tid] = x;
+		__syncthreads();
+		for (int o = 1; o < 1024; o <<= 1) {
+			const unsigned long long y = tid >= o ? sh[tid - o] : 0;
+			__syncthreads();
+			sh[tid] += y;
+			__syncthreads();
+		}
+		const unsigned long long incl = sh[tid];
+		__syncthreads();
+		return incl - x;
+	};
+	// per variant totals; budget in variant order
+	const int per = (M + 1023) / 1024, v0 = tid * per, v1 = min(M, v0 + per);
+	unsigned long long mine = 0;
+	for (int v = v0; v < v1; v++) {
+		int t = 0;
+		for (int g = 0; g < S3_NR; g++) t += cnt[(size_t)g * cap + v];
+		n3[v] = t;
+		const bool o = t > lim;
+		ovf[v] = o ? 1 : 0;
+		if (!o) mine += (unsigned long long)t;
+	}
+	unsigned long long base = block_excl(mine);
+	for (int v = v0; v < v1; v++) {
+		if (ovf[v]) continue;
+		base += (unsigned long long)n3[v];
+		if (base > (unsigned long long)idx_cap) ovf[v] = 1;
+	}
+	__syncthreads();
+	for (int v = v0; v < v1; v++)
+		if (ovf[v]) for (int g = 0; g < S3_NR; g++) cnt[(size_t)g * cap + v] = 0;
+	__syncthreads();
+	// exclusive prefix in (range, variant) order
+	const size_t tot = (size_t)S3_NR * M, per2 = (tot + 1023) / 1024;
+	const size_t e0 = (size_t)tid * per2, e1 = min(tot, e0 + per2);
+	mine = 0;
+	for (size_t e = e0; e < e1; e++) mine += (unsigned long long)cnt[(e / M) * cap + (e % M)];
+	base = block_excl(mine);
+	for (size_t e = e0; e < e1; e++) {
+		ptr[e] = (unsigned)base;
+		base += (unsigned long long)cnt[(e / M) * cap + (e % M)];
+	}
+	if (e1 == tot && e0 < tot) ptr[tot] = (unsigned)base;
+	if (tot == 0 && tid == 0) ptr[0] = 0;
+}
+
+// ---- ingest 3: the lists.  Same walk as ingest 1 over the TILED rows; the sample indices of a variant's
+// missing genotypes of range g go to idx[ptr[g M + v] ..), ascending.
+__global__ void __launch_bounds__(256)
+s3_ingest_fill_kernel(const uint8_t *__restrict__ tiles, int M, int ntile, const uint8_t *__restrict__ ovf,
+	const unsigned *__restrict__ ptr, unsigned *__restrict__ idx)
+{
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	const int frag = blockIdx.x * 4 + wid, nfrag = (M + 15) / 16;
+	if (frag >= nfrag) return;
+	const int r = lane & 15, kg = lane >> 4, v = frag * 16 + r;
+	const bool live = v < M && !ovf[v];
+	const uint8_t *src = tiles + (size_t)frag * ntile * 1024 + lane * 16;
+	constexpr int UN = 4;
+	int rg = -1, tend = 0;
+	unsigned off = 0;
+	for (int t0 = 0; t0 < ntile; t0 += UN) {
+		uint4 w[UN];
+#pragma unroll
+		for (int j = 0; j < UN; j++) {
+			w[j] = make_uint4(0u, 0u, 0u, 0u);
+			if (t0 + j < ntile) w[j] = *reinterpret_cast<const uint4 *>(src + (size_t)(t0 + j) * 1024);
+		}
+#pragma unroll
+		for (int j = 0; j < UN; j++) {
+			const int t = t0 + j;
+			if (t >= ntile) break;
+			while (t >= tend) { rg++; tend = s3_range_t0(rg + 1, ntile); off = live ? ptr[(size_t)rg * M + v] : 0u; }
+			const uint32_t d[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
+			uint32_t m[4];
+			int c = 0;
+#pragma unroll
+			for (int u = 0; u < 4; u++) { m[u] = live ? (d[u] & (d[u] >> 1) & 0x55555555u) : 0u; c += __popc(m[u]); }
+			if (!__ballot(c != 0)) continue;
+			// exclusive prefix over the four kg lanes of the variant
+			const int c0 = __shfl(c, r, 64), c1 = __shfl(c, r + 16, 64), c2 = __shfl(c, r + 32, 64), c3 = __shfl(c, r + 48, 64);
+			unsigned o = off + (kg > 0 ? c0 : 0) + (kg > 1 ? c1 : 0) + (kg > 2 ? c2 : 0);
+			off += (unsigned)(c0 + c1 + c2 + c3);
+#pragma unroll
+			for (int u = 0; u < 4; u++) {
+				uint32_t mm = m[u];
+				while (mm) {
+					const int b = __ffs(mm) - 1;
+					mm &= mm - 1;
+					idx[o++] = (unsigned)(t * 256 + kg * 64 + u * 16 + (b >> 1));
+				}
+			}
+		}
+	}
+}
+
+// ---- T3: sums of the fixed-point score values over a variant's missing samples, per sample range.
+// Q: [N][P] int64, the values the limb tiles hold (digits x position scale).  A task = (range g, variant v),
+// taken by PP lanes: lane c of the task gathers column c of every listed sample (a row of Q is P x 8 contiguous
+// bytes) and keeps hi = sum q >> 32, lo = sum q & 0xFFFFFFFF -- exact, whatever the order.  A workgroup works
+// on one range (blockIdx % S3_NR): with blocks dealt round-robin over the XCDs an L2 sees two ranges of Q
+// (1/8 of the table).  part: [S3_NR][M][P][2] int64.
+template <int PP>
+__global__ void __launch_bounds__(256)
+s3_t3_kernel(int M, int P, const long long *__restrict__ Q, const unsigned *__restrict__ ptr, const unsigned *__restrict__ idx,
+	long long *__restrict__ part)
+{
+	constexpr int TPW = 64 / PP;                       // tasks per wave
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	const int g = blockIdx.x % S3_NR, chunk = blockIdx.x / S3_NR;
+	const int c = lane % PP, tk = lane / PP;
+	const int v = (chunk * 4 + wid) * TPW + tk;
+	unsigned e0 = 0, e1 = 0;
+	if (v < M) { e0 = ptr[(size_t)g * M + v]; e1 = ptr[(size_t)g * M + v + 1]; }
+	long long hi = 0, lo = 0;
+	const int gbase = lane - c;                        // first lane of this task
+	for (unsigned e = e0; __any(e < e1); e += PP) {
+		const unsigned mine = (e + c < e1) ? idx[e + c] : 0xFFFFFFFFu;
+#pragma unroll
+		for (int j = 0; j < PP; j++) {
+			const unsigned s = (unsigned)__shfl((int)mine, gbase + j, 64);
+			if (s != 0xFFFFFFFFu && c < P) {
+				const long long q = Q[(size_t)s * P + c];
+				hi += q >> 32;
+				lo += q & 0xFFFFFFFFll;
+			}
+		}
+	}
+	if (v < M && c < P) {
+		long long *o = part + (((size_t)g * M + v) * P + c) * 2;
+		o[0] = hi; o[1] = lo;
+	}
+}
+
+// ---- the item slabs of score3_kernel -> one row of limb sums per variant (the layout the epilogue reads:
+// accbuf[v * stride + 16 b + r]).  grid = (elements of a variant tile's slab / 256, variant tiles).
+__global__ void __launch_bounds__(256)
+s3_reduce_kernel(S3Plan pl, int M, int NCW, int NAF, int NBF, const int *__restrict__ slabs, int *__restrict__ accbuf, int stride)
+{
+	const int e = blockIdx.x * 256 + threadIdx.x, per = NCW * NAF * NBF * 256, vtile = blockIdx.y;
+	if (e >= per) return;
+	const int lane = e & 63, reg = (e >> 6) & 3, fb = e >> 8;           // fb = (wave NAF + f) NBF + b
+	const int b = fb % NBF, wf = fb / NBF;                              // wf = wave NAF + f
+	const int v = (vtile * pl.fpw + wf) * 16 + (lane >> 4) * 4 + reg;
+	if (v >= M) return;
+	int sum = 0;
+	for (int g = 0; g < pl.ng; g++) {
+		int first, count;
+		s3_items_of(pl, vtile, g, first, count);
+		for (int id = first; id < first + count; id++) sum += slabs[(size_t)id * per + e];
+	}
+	accbuf[(size_t)v * stride + b * 16 + (lane & 15)] = sum;
+}
+
+// ---- epilogue: one thread per variant.  As score_mfma_epilogue, with the missing-sample sums from the T3 pass
+// and the constant column worth 4 per allele (the position scales want a multiple of 4).  Variants whose
+// missing genotypes are not listed go onto `ovf_list` (counters[23]) for the FP64 kernel.
+template <int K>
+__global__ void __launch_bounds__(256)
+score3_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf, const long long *__restrict__ t3part,
+	const int *__restrict__ n3buf, const uint8_t *__restrict__ ovf, int *__restrict__ ovf_list,
+	SpaRec *__restrict__ recs, int *__restrict__ counters, int btop, int *__restrict__ fb_series, int *__restrict__ fb_exact,
+	double *__restrict__ out8, uint8_t *__restrict__ valid)
+{
+	constexpr int P = 2 * K + 2, CW = P - 1;     // score columns c' (K), e (K), s, w; column CW carries G^2
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= M) return;
+	if (ovf[j]) { ovf_list[atomicAdd(&counters[23], 1)] = j; return; }
+	const int *a0 = accbuf + (size_t)j * ep.acc_stride;
+	const int N = md.N;
+	const int n3 = n3buf[j];
+	const long long AC = (long long)(a0[ep.col_ones] / 4) - 3ll * n3;
+	const int n2 = a0[ep.col_b1 + ep.climb[CW]] / 8 - n3;  // bit-1 plane (0/2) against the constant column (4)
+	const int n1 = (int)(AC - 2ll * n2);
+	const VarHead h = make_head(md, (double)AC, N - n3);
+	double *o = out8 + (size_t)j * 8;
+	if (!h.pass) { nan_row(o); valid[j] = 0; return; }
+	const double imp = 2 * h.AF;
+	auto t3_of = [&](int c) -> HiLo {
+		long long hi = 0, lo = 0;
+		for (int g = 0; g < S3_NR; g++) {
+			const long long *p = t3part + (((size_t)g * M + j) * P + c) * 2;
+			hi += p[0]; lo += p[1];
+		}
+		return hl(hi, lo);
+	};
+	double acc[P];
+	HiLo Wm = hl(0, 0), T3m = hl(0, 0);
+#pragma unroll
+	for (int c = 0; c < P; c++) {
+		const int cc = ep.ccol[c], nl = ep.climb[c];
+		if (nl == 0) { acc[c] = 0; continue; }            // derived below
+		const HiLo V = mf_limbs(a0 + cc, nl);
+		const HiLo T3 = t3_of(c);
+		const HiLo W = hl_axpy(-3, T3, V);
+		const double t3d = hl_to_double(T3);
+		double s;
+		if (!h.minus) s = hl_to_double(W) + imp * t3d;
+		else s = hl_to_double(hl(2 * ep.ftot_hi[c] - W.hi, 2 * ep.ftot_lo[c] - W.lo)) - imp * t3d;
+		acc[c] = ldexp(s, -ep.escale[c]);
+		if (c == CW) { Wm = W; T3m = T3; }
+	}
+	{
+		const HiLo B2 = mf_limbs(a0 + ep.col_b1, ep.climb[CW]);   // = 2 (T2 + T3), the plane holds 0/2
+		const HiLo H2 = hl(B2.hi / 2 - T3m.hi, B2.lo / 2 - T3m.lo);   // every limb sum of that plane is even
+		const double t3d = hl_to_double(T3m);
+		double w;
+		if (!h.minus) {
+			w = hl_to_double(hl_axpy(2, H2, Wm)) + imp * imp * t3d;
+		} else {
+			const HiLo S1 = hl_axpy(-2, H2, Wm);
+			const HiLo R = hl(ep.ftot_hi[CW] - S1.hi - H2.hi - T3m.hi, ep.ftot_lo[CW] - S1.lo - H2.lo - T3m.lo);
+			w = hl_to_double(hl_axpy(4, R, S1)) + (2 - imp) * (2 - imp) * t3d;
+		}
+		acc[CW] = ldexp(w, -ep.escale[CW]);
+	}
+	if (ep.derive_c) {
+#pragma unroll
+		for (int x = 0; x < K; x++) {
+			double cx = 0;
+#pragma unroll
+			for (int y = 0; y < K; y++) cx = fma(ep.XVXi[x * K + y], acc[K + y], cx);
+			acc[x] = cx;
+		}
+	}
+	double cbuf[KMAX], pn, Ssc, v2sc;
+	valid[j] = 1;
+	if (score_epilogue<(P - 2) / 2>(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
+		spa_push<K>(md, recs, counters, btop, fb_series, fb_exact, j, h.minus, h.minus ? (2 * h.Num - h.AC) : h.AC,
+			h.minus ? (N - n2) : (n1 + n2 + n3), h.lut, pn, Ssc, v2sc, cbuf);
+	}
+	atomicAdd(&counters[1], 1);
+}
+#endif /* S3_KERNEL_ONLY */

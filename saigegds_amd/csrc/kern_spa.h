@@ -15,11 +15,13 @@
 
 enum { IN_2BIT = 0, IN_U8 = 1, IN_F64 = 2 };
 
+// dosage of sample i of row r.j (2-bit rows: either layout; dosage rows: row-major)
 template <int INPUT>
-__device__ __forceinline__ double load_dosage(const void *row, int i, const SpaRec &r)
+__device__ __forceinline__ double load_dosage(const RowsRef &rr, int i, const SpaRec &r)
 {
+	const uint8_t *row = rr.base + (INPUT == IN_2BIT ? 0 : (size_t)r.j * rr.bpv);
 	if (INPUT == IN_2BIT) {
-		const uint8_t b = reinterpret_cast<const uint8_t *>(row)[i >> 2];
+		const uint8_t b = rr.base[rr_piece(rr, (size_t)r.j, (size_t)(i >> 6)) + ((i & 63) >> 2)];
 		return sel4(r.lut, (b >> ((i & 3) * 2)) & 3u);
 	} else if (INPUT == IN_U8) {
 		const uint8_t v = reinterpret_cast<const uint8_t *>(row)[i];
@@ -125,7 +127,7 @@ __device__ double saddle_prob_fast(double t, double k2s, double q, double NAmu, 
 
 template <int K, int BLOCK, int INPUT>
 __global__ void __launch_bounds__(BLOCK)
-spa_kernel(const void *__restrict__ rows, size_t row_bytes, DevModel md,
+spa_kernel(RowsRef rr, DevModel md,
 	const SpaRec *__restrict__ recs, const int *__restrict__ counters, int counter_slot,
 	const int *__restrict__ rec_index, double *__restrict__ scratch, size_t scratch_stride,
 	double *__restrict__ out8)
@@ -144,7 +146,6 @@ spa_kernel(const void *__restrict__ rows, size_t row_bytes, DevModel md,
 
 	for (int v = blockIdx.x; v < nflag; v += gridDim.x) {
 		const SpaRec r = recs[rec_index ? rec_index[v] : v];
-		const void *row = reinterpret_cast<const uint8_t *>(rows) + (size_t)r.j * row_bytes;
 		const double inv = 1 / sqrt(r.AC2);
 		double c[K];
 #pragma unroll
@@ -152,7 +153,7 @@ spa_kernel(const void *__restrict__ rows, size_t row_bytes, DevModel md,
 
 		// ---- A1: carriers per wave segment -> list offsets
 		int cnt = 0;
-		for (int i = s0 + lane; i < s1; i += WAVE) cnt += (load_dosage<INPUT>(row, i, r) != 0);
+		for (int i = s0 + lane; i < s1; i += WAVE) cnt += (load_dosage<INPUT>(rr, i, r) != 0);
 		cnt = wave_sum_i(cnt);
 		__syncthreads();            // previous variant's readers of shc/list are done
 		if (lane == 0) shc[wid] = cnt;
@@ -168,7 +169,7 @@ spa_kernel(const void *__restrict__ rows, size_t row_bytes, DevModel md,
 			const bool in = i < s1;
 			double G = 0, adj = 0, mui = 0;
 			if (in) {
-				G = load_dosage<INPUT>(row, i, r);
+				G = load_dosage<INPUT>(rr, i, r);
 				const double *x = md.X + (size_t)i * K;
 				double d = 0;
 #pragma unroll

@@ -182,7 +182,7 @@ __device__ __forceinline__ void spa4_queue_done(int *cursor)
 // consecutive samples of the segment and walks its carriers in lock step with the other lanes.
 template <int K, int NC>
 __global__ void __launch_bounds__(WAVE * spa4_waves(K))
-spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int nseg, int tier, int btop, int v0, int vcap,
+spa4_moments(RowsRef rr, DevModel md, int nseg, int tier, int btop, int v0, int vcap,
 	const SpaRec *__restrict__ recs, const int *__restrict__ counters, double *__restrict__ segpart, int abl, int *__restrict__ cursor)
 {
 	constexpr int SEG = spa_seg(K), KP = (K + 2) & ~1, NS = NC + 5;
@@ -205,13 +205,13 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 	const int nitem = nseg * nslice;
 	__shared__ int sh_it;
 	int seg = -1;
-	size_t row_off = 0;                                                           // this lane's bytes of a row
+	size_t row_off = 0;                                                           // this lane's bytes of a row (piece 16 B = 64 samples)
 	bool mine = false;
 	int samp0 = 0;                                                                // first sample of the lane
 	auto load_row = [&](int vl) -> uint4 {                                      // .x .. of the first LDW are used
 		uint4 w = make_uint4(0u, 0u, 0u, 0u);
 		if (mine && !(abl & 16)) {
-			const uint8_t *p = packed + (size_t)pj[vl] * bpv + row_off;
+			const uint8_t *p = rr.base + rr_piece(rr, (size_t)pj[vl], row_off >> 4) + (row_off & 15);
 			if (LDW == 4) w = *reinterpret_cast<const uint4 *>(p);
 			else if (LDW == 2) { const uint2 t = *reinterpret_cast<const uint2 *>(p); w.x = t.x; w.y = t.y; }
 			else w.x = *reinterpret_cast<const uint32_t *>(p);
@@ -231,7 +231,7 @@ spa4_moments(const uint8_t *__restrict__ packed, size_t bpv, DevModel md, int ns
 			const int rows = min(SEG, N - seg * SEG);
 			spa4_stage_table<spa4_waves(K)>(tab, md.XM + (size_t)seg * SEG * KP, rows * KP);
 			row_off = ((size_t)seg * (SEG / 16) + (size_t)lane * LDW) * 4;
-			mine = lane < NLANE && row_off + 4 * LDW <= bpv;
+			mine = lane < NLANE && row_off + 4 * LDW <= rr_row_bytes(rr);
 			samp0 = seg * SEG + lane * LDW * 16;
 		}
 		for (int i = tid; i < nv; i += WAVE * spa4_waves(K)) {
@@ -785,7 +785,7 @@ __device__ __forceinline__ bool spa5_series(const double2 *__restrict__ glist, i
 #endif
 template <int K, int INPUT, int MODE, int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
-spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec *__restrict__ recs,
+spa5_kernel(RowsRef rr, DevModel md, const SpaRec *__restrict__ recs,
 	int *__restrict__ counters, const int *__restrict__ todo, int *__restrict__ todo_next, int *__restrict__ cursor,
 	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8, int force_dense, int force_exact,
 	size_t lds_row_bytes)
@@ -803,7 +803,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 	uint32_t *ilist = reinterpret_cast<uint32_t *>(glist + (((size_t)N + 63) & ~(size_t)63));
 	const int ntodo = counters[MODE == 0 ? 3 : 4];
 	// pieces of 64 samples: a uint4 of a packed row, or 64 dosages
-	const int nvec = INPUT == IN_2BIT ? (int)(min((size_t)((N + 63) >> 6) * 16, bpv) / 16) : (N + 63) >> 6;
+	const int nvec = INPUT == IN_2BIT ? (int)(min((size_t)((N + 63) >> 6) * 16, rr_row_bytes(rr)) / 16) : (N + 63) >> 6;
 	const int per = ((nvec + NW - 1) / NW + WAVE - 1) & ~(WAVE - 1);          // pieces per wave, whole wave steps
 	for (;;) {
 		__syncthreads();                         // sh_vi, shi and the lists of the previous variant are free
@@ -832,8 +832,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 		const int v = sh_v;
 		const SpaRec &r = sh_rec;
 		if ((r.nnz > SPA5_BIG) != big_round) continue;
-		const uint8_t *rowb = reinterpret_cast<const uint8_t *>(rows) + (size_t)r.j * bpv;
-		const uint4 *row = reinterpret_cast<const uint4 *>(rowb);
+		auto row_piece = [&](int p) -> uint4 { return *reinterpret_cast<const uint4 *>(rr.base + rr_piece(rr, (size_t)r.j, (size_t)p)); };
 		const uint32_t zx = r.minus ? 0xAAAAAAAAu : 0u;
 		const double lut0 = r.lut[0], lut1 = r.lut[1], lut2 = r.lut[2], lut3 = r.lut[3];
 		// ---- index list: sample | code << 30, ascending.  Wave w owns pieces [w per, (w+1) per).
@@ -847,7 +846,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			for (int p0 = tid; p0 < nvec; p0 += UN * BLOCK) {
 				uint4 t[UN];
 #pragma unroll
-				for (int j = 0; j < UN; j++) { const int p = p0 + j * BLOCK; t[j] = p < nvec ? row[p] : make_uint4(0u, 0u, 0u, 0u); }
+				for (int j = 0; j < UN; j++) { const int p = p0 + j * BLOCK; t[j] = p < nvec ? row_piece(p) : make_uint4(0u, 0u, 0u, 0u); }
 #pragma unroll
 				for (int j = 0; j < UN; j++) { const int p = p0 + j * BLOCK; if (p < nvec) rows_lds[p] = t[j]; }
 			}
@@ -858,7 +857,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 			int cnt = 0;
 			if (INPUT == IN_2BIT) {
 				uint4 w = make_uint4(0u, 0u, 0u, 0u);
-				if (p < nvec) w = staged ? rows_lds[p] : row[p];
+				if (p < nvec) w = staged ? rows_lds[p] : row_piece(p);
 				ww[0] = w.x; ww[1] = w.y; ww[2] = w.z; ww[3] = w.w;
 #pragma unroll
 				for (int k = 0; k < 4; k++) { z[k] = nz_fields((ww[k] ^ zx) & keep_mask(N - p * 64 - 16 * k)); cnt += __popc(z[k]); }
@@ -867,7 +866,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 				if (p < nvec) {
 					for (int s2 = 0; s2 < 64; s2++) {
 						const int i = p * 64 + s2;
-						if (i < N && load_dosage<INPUT>(rowb, i, r) != 0) { z[s2 >> 5] |= 1u << (s2 & 31); cnt++; }
+						if (i < N && load_dosage<INPUT>(rr, i, r) != 0) { z[s2 >> 5] |= 1u << (s2 & 31); cnt++; }
 					}
 				}
 			}
@@ -951,7 +950,7 @@ spa5_kernel(const void *__restrict__ rows, size_t bpv, DevModel md, const SpaRec
 				if (k >= nnz) continue;
 				const uint32_t code = e[j] >> 30;
 				const double G = INPUT == IN_2BIT ? ((code & 2u) ? ((code & 1u) ? lut3 : lut2) : ((code & 1u) ? lut1 : lut0))
-					: load_dosage<INPUT>(rowb, (int)(e[j] & 0x3FFFFFFFu), r);
+					: load_dosage<INPUT>(rr, (int)(e[j] & 0x3FFFFFFFu), r);
 				double b = 0;
 #pragma unroll
 				for (int a = 0; a < K; a++) b = fma(xv[j][a], c[a], b);

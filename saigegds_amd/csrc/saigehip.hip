@@ -60,6 +60,7 @@ static int fail(int code, const char *fmt, ...)
 #include "dev_common.h"
 #include "kern_score.h"
 #include "kern_score_mfma.h"
+#include "kern_score3.h"
 #include "kern_spa.h"
 #include "kern_spa2.h"
 #include "kern_spa4.h"
@@ -70,6 +71,22 @@ static int fail(int code, const char *fmt, ...)
 
 // ---------------------------------------------------------------------------
 // host side
+
+// A block of variants in the tiled device layout (s3_layout.h) with the lists of its missing genotypes.
+// Depends on the number of samples only: one block can be scanned with any model of that many samples.
+struct sgx_block {
+	int device = 0;
+	int N = 0, ntile = 0;
+	size_t cap = 0;              // variants it can hold
+	size_t M = 0;                // variants loaded
+	uint8_t *tiles = nullptr;    // [ceil(cap / 16)][ntile][1024]
+	int *cnt = nullptr;          // [S3_NR][cap] listed missing genotypes per (sample range, variant)
+	unsigned *ptr = nullptr;     // [S3_NR * cap + 1] offsets into idx in (range, variant) order
+	unsigned *idx = nullptr;     // sample indices of the listed missing genotypes
+	size_t idx_cap = 0;
+	int *n3 = nullptr;           // [cap] missing genotypes per variant (listed or not)
+	uint8_t *ovf = nullptr;      // [cap] 1 = not listed (too many): the scan takes the FP64 kernel for it
+};
 
 struct sgx_handle {
 	int device = 0;
@@ -97,7 +114,14 @@ struct sgx_handle {
 	int mf_nbfv[MF_MAXG]{};
 	MfEpi mfe{};
 	uint8_t *dFl = nullptr;
+	long long *dQ = nullptr;          // [N][P] the fixed-point score values as int64 (s3_t3_kernel)
 	int *mf_acc = nullptr;
+	// score3 (kern_score3.h): item slabs, partial sums over the missing samples, variants for the FP64 kernel
+	int *s3_slabs = nullptr; size_t s3_slabs_cap = 0;
+	long long *s3_t3 = nullptr; size_t s3_t3_cap = 0;
+	int *s3_ovf = nullptr; size_t s3_ovf_cap = 0;
+	bool s3_attr[17] = {false};       // per NBF: dynamic LDS size raised
+	sgx_block *tmp_blk[2] = {nullptr, nullptr};   // row-major calls: the rows are ingested into a block first
 	int n_cu = 256;
 	int *counters = nullptr;          // [0] n_spa, [1] n_valid, [2] n_fallback
 	int *h_counters = nullptr;        // pinned
@@ -313,33 +337,35 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		f[2 * K] = m->y_mu[i];
 		f[2 * K + 1] = w;
 	}
-	// fixed-point limb tables for the MFMA score path (binary and quantitative alike), one per
-	// column group (kern_score_mfma.h "Limb counts", "Column groups")
+	// Fixed-point limb tiles of the MFMA score path (kern_score3.h; kern_score_mfma.h "Limb counts"): ONE
+	// group of up to 15 value fragments + the bit-1 fragment, and the table Q of the same values as int64
+	// for the sparse pass over the missing genotypes.  Sample x at an odd position of its dword is used by
+	// the kernel where it stands, two bits up (s3_scale): its value is a multiple of 4 and its digits carry
+	// value / 4.
 	std::vector<int8_t> Fl;
-	std::vector<size_t> fl_off;
-	if ((double)N * 384.0 < 2147483647.0) {
+	std::vector<long long> Qt;
+	if ((double)N * 4.0 * 384.0 < 2147483647.0) {
 		MfEpi &ep = h->mfe;
 		const int CS = 2 * K, CW = 2 * K + 1;       // s, and the column that carries G^2 (w)
 		const int ngrp = (N + 15) / 16;
-		const int ntile = 2 * ((ngrp + 31) / 32);   // even: the wide-row kernel walks pairs of tiles
+		const int ntile = 2 * ((ngrp + 31) / 32);   // whole 128-B lines of a row-major row
 		const size_t ngrp_pad = (size_t)ntile * 16;
-		// pack the columns: s, w and the constant 1 first (group 0), then e, then c'
-		// Quantitative traits: the weights are 1 (saige_main.cpp:227-228), so w is the constant-1
-		// column (one limb) and t_XVX_inv_XV = X (X'X)^-1 makes c' a K x K image of e = sum G X:
-		// the c' columns are not carried, the epilogue forms c' = XVXi e (XVXi fitted to the model's
-		// own t_XVX_inv_XV, fit_xvx_inverse).  Binary traits keep them: there the two weight vectors
-		// (no-K V in t_XVX_inv_XV, GLMM mu2 in e) differ.
+		// the columns: s, w first, then e, then c'.  Quantitative traits: the weights are 1
+		// (saige_main.cpp:227-228), so w is the constant column (one limb) and t_XVX_inv_XV = X (X'X)^-1
+		// makes c' a K x K image of e = sum G X: the c' columns are not carried, the epilogue forms
+		// c' = XVXi e (XVXi fitted to the model's own t_XVX_inv_XV, fit_xvx_inverse).  Binary traits keep
+		// them: there the two weight vectors (no-K V in t_XVX_inv_XV, GLMM mu2 in e) differ.
 		ep.derive_c = quant && fit_xvx_inverse(m, ep.XVXi) ? 1 : 0;
 		std::vector<int> order = {CS, CW};
 		for (int k = 0; k < K; k++) order.push_back(K + k);
 		if (!ep.derive_c) for (int k = 0; k < K; k++) order.push_back(k);
 		for (int k = 0; k < K; k++) { ep.cgrp[k] = 0; ep.ccol[k] = 0; ep.climb[k] = 0; }
 		// Limb counts follow the measured dynamic range of each column.  A column is quantised against
-		// its largest entry, so an entry of typical size keeps 8 nl - 2 - log2(max / typical) bits: the
-		// reduced widths of kern_score_mfma.h "Limb counts" hold for covariates whose largest value is
-		// a few times the typical one (max / mean|.| = 5.6 for a standard normal column at N = 430 000)
-		// and are widened for heavy-tailed ones; beyond 2^22 no width is enough and the model takes the
-		// FP64 gather kernels instead of the MFMA path.
+		// its largest entry, so an entry of typical size keeps 8 nl - 2 - log2(max / typical) bits (two
+		// fewer at the odd positions): the reduced widths of kern_score_mfma.h "Limb counts" hold for
+		// covariates whose largest value is a few times the typical one (max / mean|.| = 5.6 for a standard
+		// normal column at N = 430 000) and are widened for heavy-tailed ones; beyond 2^22 no width is
+		// enough and the model takes the FP64 gather kernels instead of the MFMA path.
 		bool range_ok = true;
 		auto limbs_for = [&](int c) -> int {
 			if (c == CW && quant) return 1;
@@ -350,72 +376,54 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 			int nl = c >= 2 * K ? MF_NLIMB : (c >= K ? MF_LIMB_E : MF_LIMB_A);
 			if (range > 64.0) nl = std::max(nl, MF_LIMB_E);
 			if (range > 16384.0) nl = MF_NLIMB;
+			// Small models: a sum over a handful of carriers does not average the quantisation away, and the
+			// odd sample positions keep two bits fewer (s3_scale) -- one more limb costs nothing that matters
+			// at these sizes (constructed inputs at N = 200: p-value 1.2e-10 off with the reduced widths)
+			if (N < 16384) nl = std::min(MF_NLIMB, nl + 1);
 			return nl;
 		};
-		// Column groups, filled in order (a column is never cut).  Group 0 also carries the bit-1 fragment:
-		// with 3 value fragments it runs the 3-waves-per-SIMD form of the kernel, with 4 the slower
-		// 2-waves one -- so when more than one group is needed anyway, group 0 is filled to 48 columns only,
-		// unless that costs an extra group (an extra pass over the rows).
-		int nlimb[MF_MAXP];
-		for (int c : order) nlimb[c] = limbs_for(c);
-		int g = 0, used = 1, glimbs[MF_MAXG] = {0};   // group 0: one column for the constant 1
-		auto plan = [&](int cap0, bool commit) -> int {
-			int gg = 0, uu = 1;
-			for (int c : order) {
-				const int nl = nlimb[c];
-				if (uu + nl > (gg == 0 ? cap0 : MF_GLIMBS)) { if (commit) glimbs[gg] = uu; gg++; uu = 0; }
-				if (gg >= MF_MAXG) return MF_MAXG + 1;
-				if (commit) { ep.cgrp[c] = (unsigned char)gg; ep.ccol[c] = (unsigned char)(uu - (gg == 0 ? 1 : 0)); ep.climb[c] = (unsigned char)nl; }
-				uu += nl;
-			}
-			if (commit) { g = gg; used = uu; }
-			return gg + 1;
-		};
-		{
-			const int n64 = plan(MF_GLIMBS, false), n48 = plan(48, false);
-			const int cap0 = (n64 > 1 && n48 == n64) ? 48 : MF_GLIMBS;
-			if (plan(cap0, true) > MF_MAXG) range_ok = false;
+		int used = 1;                               // column 0 .. : values; the constant column last
+		for (int c : order) {
+			const int nl = limbs_for(c);
+			ep.cgrp[c] = 0; ep.ccol[c] = (unsigned char)(used - 1); ep.climb[c] = (unsigned char)nl;
+			used += nl;
 		}
 		if (range_ok) {
-		glimbs[g] = used;
-		ep.ngroups = g + 1;
-		int off = 0;
-		size_t bytes = 0;
-		for (g = 0; g < ep.ngroups; g++) {
-			const int nb = (glimbs[g] + 15) / 16;
-			h->mf_nbfv[g] = nb;
-			ep.gncol[g] = 16 * (nb + (g == 0 ? 1 : 0));
-			ep.goff[g] = off;
-			off += ep.gncol[g] + 16 * nb;
-			fl_off.push_back(bytes);
-			bytes += ngrp_pad * ep.gncol[g] * 16;
-			h->mf[g].ntile = ntile;
-		}
-		ep.acc_stride = off;
-		ep.col_ones = glimbs[0] - 1;                // after group 0's value columns
-		ep.col_b1 = 16 * h->mf_nbfv[0];
-		Fl.assign(bytes, 0);
-		auto at = [&](int gg, int i, int col) -> int8_t & {
-			return Fl[fl_off[gg] + ((size_t)(i / 16) * ep.gncol[gg] + col) * 16 + mf_pos(i % 16)];
+		const int nbfv = (used + 15) / 16;          // value fragments (<= 15: 2 K x 7 + 7 + 7 + 1 <= 239 columns)
+		h->mf_nbfv[0] = nbfv;
+		ep.ngroups = 1;
+		ep.goff[0] = 0;
+		ep.gncol[0] = 16 * (nbfv + 1);
+		ep.acc_stride = ep.gncol[0];
+		ep.col_ones = used - 1;                     // after the value columns
+		ep.col_b1 = 16 * nbfv;
+		h->mf[0].ntile = ntile;
+		Fl.assign(ngrp_pad * ep.gncol[0] * 16, 0);
+		Qt.assign((size_t)N * P, 0);
+		auto at = [&](int i, int col) -> int8_t & {
+			return Fl[((size_t)(i / 16) * ep.gncol[0] + col) * 16 + s3_pos(i % 16)];
 		};
 		for (int c = 0; c < P; c++) {
-			const int gg = ep.cgrp[c], cc = ep.ccol[c], nl = ep.climb[c];
+			const int cc = ep.ccol[c], nl = ep.climb[c];
 			if (nl == 0) { ep.escale[c] = 0; ep.ftot_hi[c] = ep.ftot_lo[c] = 0; continue; }   // derived column
 			double mx = 0;
 			for (int i = 0; i < N; i++) mx = std::max(mx, std::fabs(F[(size_t)i * P + c]));
 			int ex = 0;
 			if (mx > 0) (void)std::frexp(mx, &ex);
-			ep.escale[c] = (quant && c == CW) ? 0 : 8 * nl - 2 - ex;   // quantitative w = 1 exactly: q = 1
+			ep.escale[c] = (quant && c == CW) ? 2 : 8 * nl - 2 - ex;   // quantitative w = 1 exactly: value 4
 			__int128 tot = 0;
 			for (int i = 0; i < N; i++) {
-				long long q = std::llrint(std::ldexp(F[(size_t)i * P + c], ep.escale[c]));
+				const int sc = s3_scale(i % 16);
+				const long long d0 = std::llrint(std::ldexp(F[(size_t)i * P + c], ep.escale[c]) / sc);   // digits hold value / scale
+				const long long q = d0 * sc;
+				Qt[(size_t)i * P + c] = q;
 				tot += q;
-				long long rem = q;
+				long long rem = d0;
 				for (int l = 0; l < nl; l++) {
 					long long d = (l < nl - 1) ? (((rem + 128) & 255) - 128) : rem;
 					rem = (rem - d) >> 8;
-					at(gg, i, cc + l) = (int8_t)d;
-					if (c == CW) at(0, i, ep.col_b1 + l) = (int8_t)d;
+					at(i, cc + l) = (int8_t)d;
+					if (c == CW) at(i, ep.col_b1 + l) = (int8_t)d;
 				}
 			}
 			const __int128 two32 = ((__int128)1) << 32;
@@ -423,9 +431,10 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 			if (lo < 0) { lo += two32; hi -= 1; }
 			ep.ftot_hi[c] = (long long)hi; ep.ftot_lo[c] = (long long)lo;
 		}
-		for (int i = 0; i < N; i++) {
-			at(0, i, ep.col_ones) = 1;
-			at(0, i, ep.col_b1 + ep.climb[CW]) = 1;
+		for (int i = 0; i < N; i++) {               // the constant column: 4 per allele at every position
+			const int8_t d = (int8_t)(4 / s3_scale(i % 16));
+			at(i, ep.col_ones) = d;
+			at(i, ep.col_b1 + ep.climb[CW]) = d;
 		}
 		h->mf_ok = true;
 		}
@@ -461,7 +470,8 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 	if (h->mf_ok) {
 		std::vector<uint8_t> Flu(Fl.begin(), Fl.end());
 		TRY(dev_upload(&h->dFl, Flu));
-		for (int g = 0; g < h->mfe.ngroups; g++) h->mf[g].Fl = h->dFl + fl_off[g];
+		h->mf[0].Fl = h->dFl;
+		TRY(dev_upload(&h->dQ, Qt));
 	}
 	md.F = h->dF; md.X = h->dX; md.y = h->dy; md.mu = h->dmu; md.mu2 = h->dmu2; md.XM = h->dXM;
 	rc = alloc_workspace(h);
@@ -490,9 +500,11 @@ extern "C" void sgx_free(sgx_handle *h)
 	if (h->twin) { sgx_free(h->twin); h->twin = nullptr; }
 	if (!h->shares_model) {
 		(void)hipFree(h->dF); (void)hipFree(h->dX); (void)hipFree(h->dy);
-		(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->dFl);
+		(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->dFl); (void)hipFree(h->dQ);
 	}
 	(void)hipFree(h->fallback); (void)hipFree(h->fb_spa2); (void)hipFree(h->fb_x2);
+	(void)hipFree(h->s3_slabs); (void)hipFree(h->s3_t3); (void)hipFree(h->s3_ovf);
+	for (int b = 0; b < 2; b++) if (h->tmp_blk[b]) { sgx_block_free(h->tmp_blk[b]); h->tmp_blk[b] = nullptr; }
 	(void)hipFree(h->mf_acc); (void)hipFree(h->seg4); (void)hipFree(h->scr5); (void)hipFree(h->cur5);
 	(void)hipFree(h->recs); (void)hipFree(h->counters); (void)hipFree(h->scratch);
 	for (int b = 0; b < 2; b++) {
@@ -565,60 +577,123 @@ static dim3 mf_grid(int n_cu, size_t rows, int ntile, int *tps, int vpb = MF_VPB
 	return dim3((unsigned)vt, (unsigned)sk);
 }
 
+// SPA stage of the flagged variants of a call (their records are in h->recs): the series kernels
+// (kern_spa4.h), the per-variant kernels and the exact dense pass.  rr: the call's rows.
+template <int INPUT>
+static int launch_spa(sgx_handle *h, RowsRef rr, size_t M, double *out8)
+{
+	const DevModel &md = h->md;
+	constexpr int PB = 512;
+	hipStream_t st = h->stream;
+	h->stats.spa_launches = 0;
+	if (!md.quant) {
+		const dim3 sgrid((unsigned)std::min<size_t>(M, (size_t)h->spa_grid));
+		switch (md.K) {
+#define MOMENTS(KK, NCX, TIER, RD)                                                               \
+	do {                                                                                         \
+		if (INPUT == IN_2BIT)                                                                    \
+			hipLaunchKernelGGL((spa4_moments<KK, NCX>), dim3((unsigned)h->n_cu), \
+				dim3(WAVE * spa4_waves(KK)), fl, st, rr, md, h->nseg,  \
+				TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl, h->cur5 + 2); \
+		else                                                                                     \
+			hipLaunchKernelGGL((spa4_moments_ds<KK, NCX, (INPUT == IN_2BIT ? IN_U8 : INPUT)>),   \
+				dim3((unsigned)h->n_cu), dim3(WAVE * spa4_waves(KK)), fl, st, (const void *)rr.base, rr.bpv, md, \
+				h->nseg, TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->cur5 + 2);  \
+		hipLaunchKernelGGL((spa4_solve<KK, NCX>), gsolve, dim3(256), 0, st, md, h->nseg, TIER,   \
+			btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->fallback,         \
+			h->fb_x2, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0);                     \
+	} while (0)
+#define CASE(KK)                                                                             \
+	case KK:                                                                                 \
+		if (h->force_v1 && INPUT != IN_2BIT) {                                               \
+			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rr,    \
+				md, h->recs, h->counters, 0, (const int *)nullptr, h->scratch,    \
+				h->scratch_stride, out8);                                                    \
+		} else {                                                                             \
+			/* series SPA stage (kern_spa4.h): rounds of at most vcap4 flagged variants;     \
+			   tier A (short series), then tier B with what tier A handed on */              \
+			const size_t fl = spa4_lds_bytes(KK);                                            \
+			if (!h->mom_attr_set[INPUT]) {                                                   \
+				const void *fa = INPUT == IN_2BIT ? (const void *)spa4_moments<KK, SPA4_NCA> \
+					: (const void *)spa4_moments_ds<KK, SPA4_NCA, (INPUT == IN_2BIT ? IN_U8 : INPUT)>; \
+				const void *fb = INPUT == IN_2BIT ? (const void *)spa4_moments<KK, SPA4_NCB> \
+					: (const void *)spa4_moments_ds<KK, SPA4_NCB, (INPUT == IN_2BIT ? IN_U8 : INPUT)>; \
+				HIPCHK(hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl)); \
+				HIPCHK(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl)); \
+				h->mom_attr_set[INPUT] = true;                                               \
+			}                                                                                \
+			const int nround = (int)((M + h->vcap4 - 1) / h->vcap4);                         \
+			const int btop = (int)(2 * M);                                                   \
+			const dim3 gsolve((unsigned)std::min((h->vcap4 + 3) / 4, 4 * h->n_cu));   /* a wave per variant, grid-stride */ \
+			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCA, 0, rd);                \
+			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCB, 1, rd);                \
+			/* what the series does not cover: exact exp/log sums, one workgroup per variant; \
+			   then the exact dense g_pos / g_neg pass */                                    \
+			/* a packed row in LDS when it fits; short rows: 128 threads per variant, 4 workgroups per CU */ \
+			const size_t rowb5 = (size_t)((md.N + 63) / 64) * 16;                            \
+			const size_t l5 = (INPUT == IN_2BIT && rowb5 <= 120 * 1024) ? rowb5 : 0;         \
+			const bool small5 = INPUT == IN_2BIT && rowb5 <= 32 * 1024;                      \
+			if (l5 > 48 * 1024 && !h->spa5_attr_set[INPUT]) {                                \
+				HIPCHK(hipFuncSetAttribute((const void *)spa5_kernel<KK, INPUT, 0, 512>,     \
+					hipFuncAttributeMaxDynamicSharedMemorySize, (int)l5));                   \
+				HIPCHK(hipFuncSetAttribute((const void *)spa5_kernel<KK, INPUT, 1, 512>,     \
+					hipFuncAttributeMaxDynamicSharedMemorySize, (int)l5));                   \
+				h->spa5_attr_set[INPUT] = true;                                              \
+			}                                                                                \
+			const int fx5 = (h->force_exact ? 1 : 0) | (h->spa_abl & ~1);                    \
+			if (small5) {                                                                    \
+				/* (2-bit rows only: the constant keeps the other inputs' 128-thread forms uninstantiated) */ \
+				constexpr int IN5 = INPUT == IN_2BIT ? INPUT : IN_2BIT;                      \
+				hipLaunchKernelGGL((spa5_kernel<KK, IN5, 0, 128>), dim3((unsigned)h->nwg5), dim3(128), \
+					l5, st, rr, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+				hipLaunchKernelGGL((spa5_kernel<KK, IN5, 1, 128>), dim3((unsigned)h->nwg5), dim3(128), \
+					l5, st, rr, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+			} else {                                                                         \
+				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 0, 512>), dim3((unsigned)h->n_cu), dim3(512), \
+					l5, st, rr, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 1, 512>), dim3((unsigned)h->n_cu), dim3(512), \
+					l5, st, rr, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+			}                                                                                \
+			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rr,    \
+				md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
+				h->scratch_stride, out8);                                                    \
+		}                                                                                    \
+		break;
+			FOR_EACH_K(CASE)
+#undef CASE
+#undef MOMENTS
+		}
+		HIPCHK(hipGetLastError());
+		h->stats.spa_launches = (h->force_v1 && INPUT != IN_2BIT) ? 1u : (uint32_t)(4 * ((M + h->vcap4 - 1) / h->vcap4) + 3);
+	}
+	return SGX_OK;
+}
+
+// Score stage by the FP64 kernels (dosage rows; 2-bit rows of the "score_v1" hook or of a model the
+// fixed-point form does not hold), then the SPA stage.  Row-major rows.
 template <int INPUT>
 static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t M,
 	double *out8, uint8_t *valid)
 {
 	const DevModel &md = h->md;
-	constexpr int SB = 256, PB = 512;
+	constexpr int SB = 256;
 	hipStream_t st = h->stream;
+	const RowsRef rr{reinterpret_cast<const uint8_t *>(rows), row_bytes, 0};
 	HIPCHK(hipMemsetAsync(h->counters, 0, 24 * sizeof(int), st));
 	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 4 * sizeof(int), st));
 	HIPCHK(hipEventRecord(h->ev[0], st));
-	const bool use_mf = (INPUT == IN_2BIT) && h->mf_ok && !h->force_v1;
-	if (use_mf) {
-		const MfEpi &ep = h->mfe;
-		HIPCHK(hipMemsetAsync(h->mf_acc, 0, M * (size_t)ep.acc_stride * sizeof(int), st));
-		// wide rows where the registers allow it
-		const bool wide = row_bytes % 128 == 0 && (size_t)h->mf[0].ntile * 64 <= row_bytes;
-		for (int g = 0; g < ep.ngroups; g++) {
-			const size_t lds = (size_t)2 * 16 * ep.gncol[g] * 16;
-			int *acc = h->mf_acc + ep.goff[g];
-			// NAF_ = 3 A fragments per wave: 3 waves per SIMD (<= 168 registers) instead of 2 -- 6 % faster at
-			// K = 3 although each B fragment read then feeds 3 MFMAs instead of 4; used wherever it fits
-			// without spilling (not: 4 value fragments + bit-1 fragment; 3 + bit-1 only with narrow rows)
-#define MFRUN(NB, B1, WIDE_, NAF_)                                                             \
-	do { int tps = 0;                                                                          \
-		const dim3 mgrid = mf_grid(h->n_cu, M, h->mf[g].ntile, &tps, 16 * NAF_ * MF_WAVES, NAF_ == 3 ? 3 : 2); \
-		hipLaunchKernelGGL((score_mfma_kernel<NB, B1, WIDE_, 0, NAF_>), mgrid, dim3(WAVE * MF_WAVES), lds, st, \
-			(const uint8_t *)rows, row_bytes, (int)M, h->mf[g], tps, acc, ep.acc_stride); } while (0)
-			const int nb = h->mf_nbfv[g];
-			if (g == 0) {
-				if (nb == 2) { if (wide) MFRUN(2, true, true, 3); else MFRUN(2, true, false, 3); }
-				else if (nb == 3) MFRUN(3, true, false, 3);
-				else MFRUN(4, true, false, 4);
-			} else {
-				if (nb == 1) MFRUN(1, false, false, 3); else if (nb == 2) MFRUN(2, false, false, 3);
-				else if (nb == 3) MFRUN(3, false, false, 3); else MFRUN(4, false, false, 3);
-			}
-#undef MFRUN
-		}
-		switch (md.K) {
-#define ECASE(KK) case KK:                                                                     \
-	hipLaunchKernelGGL((score_mfma_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), \
-		0, st, (int)M, md, ep, h->mf_acc, h->recs, h->counters, md.quant ? 0 : (int)(2 * M), h->fb_spa2, h->fb_x2, out8, valid); break;
-		FOR_EACH_K(ECASE)
-#undef ECASE
-		default: return fail(SGX_EINVAL, "MFMA score path: unsupported K=%d", md.K);
-		}
-	} else {
+	{
 	const dim3 grid((unsigned)M);
 		switch (md.K) {
 	#define CASE(KK)                                                                             \
 		case KK:                                                                                 \
 			if (INPUT == IN_2BIT)                                                                \
 				hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, SB>), grid, dim3(SB), 0, st,     \
-					(const uint8_t *)rows, row_bytes, (int)M, md, h->recs, h->counters, out8, valid); \
+					rr, (int)M, md, h->recs, h->counters, out8, valid, (const int *)nullptr, 0, 0, (int *)nullptr, (int *)nullptr); \
 			else if (KK <= 8 && !h->force_v1) {                                                  \
 				/* tiled one-pass kernels: 32 variants x a sample range per workgroup */         \
 				constexpr int PT = (KK <= 8) ? 2 * KK + 2 : 4;                                   \
@@ -657,92 +732,9 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[1], st));
-	h->stats.score_launches = use_mf ? 2 : 1;
-	h->stats.spa_launches = 0;
-	if (!md.quant) {
-		const dim3 sgrid((unsigned)std::min<size_t>(M, (size_t)h->spa_grid));
-		switch (md.K) {
-#define MOMENTS(KK, NCX, TIER, RD)                                                               \
-	do {                                                                                         \
-		if (INPUT == IN_2BIT)                                                                    \
-			hipLaunchKernelGGL((spa4_moments<KK, NCX>), dim3((unsigned)h->n_cu), \
-				dim3(WAVE * spa4_waves(KK)), fl, st, (const uint8_t *)rows, row_bytes, md, h->nseg,  \
-				TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->spa_abl, h->cur5 + 2); \
-		else                                                                                     \
-			hipLaunchKernelGGL((spa4_moments_ds<KK, NCX, (INPUT == IN_2BIT ? IN_U8 : INPUT)>),   \
-				dim3((unsigned)h->n_cu), dim3(WAVE * spa4_waves(KK)), fl, st, rows, row_bytes, md, \
-				h->nseg, TIER, btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->cur5 + 2);  \
-		hipLaunchKernelGGL((spa4_solve<KK, NCX>), gsolve, dim3(256), 0, st, md, h->nseg, TIER,   \
-			btop, (RD) * h->vcap4, h->vcap4, h->recs, h->counters, h->seg4, h->fallback,         \
-			h->fb_x2, out8, h->force_dense ? 1 : 0, h->force_exact ? 1 : 0);                     \
-	} while (0)
-#define CASE(KK)                                                                             \
-	case KK:                                                                                 \
-		if (h->force_v1 && INPUT != IN_2BIT) {                                               \
-			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
-				row_bytes, md, h->recs, h->counters, 0, (const int *)nullptr, h->scratch,    \
-				h->scratch_stride, out8);                                                    \
-		} else {                                                                             \
-			/* series SPA stage (kern_spa4.h): rounds of at most vcap4 flagged variants;     \
-			   tier A (short series), then tier B with what tier A handed on */              \
-			const size_t fl = spa4_lds_bytes(KK);                                            \
-			if (!h->mom_attr_set[INPUT]) {                                                   \
-				const void *fa = INPUT == IN_2BIT ? (const void *)spa4_moments<KK, SPA4_NCA> \
-					: (const void *)spa4_moments_ds<KK, SPA4_NCA, (INPUT == IN_2BIT ? IN_U8 : INPUT)>; \
-				const void *fb = INPUT == IN_2BIT ? (const void *)spa4_moments<KK, SPA4_NCB> \
-					: (const void *)spa4_moments_ds<KK, SPA4_NCB, (INPUT == IN_2BIT ? IN_U8 : INPUT)>; \
-				HIPCHK(hipFuncSetAttribute(fa, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl)); \
-				HIPCHK(hipFuncSetAttribute(fb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fl)); \
-				h->mom_attr_set[INPUT] = true;                                               \
-			}                                                                                \
-			const int nround = (int)((M + h->vcap4 - 1) / h->vcap4);                         \
-			const int btop = (int)(2 * M);                                                   \
-			const dim3 gsolve((unsigned)std::min((h->vcap4 + 3) / 4, 4 * h->n_cu));   /* a wave per variant, grid-stride */ \
-			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCA, 0, rd);                \
-			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCB, 1, rd);                \
-			/* what the series does not cover: exact exp/log sums, one workgroup per variant; \
-			   then the exact dense g_pos / g_neg pass */                                    \
-			/* a packed row in LDS when it fits; short rows: 128 threads per variant, 4 workgroups per CU */ \
-			const size_t rowb5 = (size_t)((md.N + 63) / 64) * 16;                            \
-			const size_t l5 = (INPUT == IN_2BIT && rowb5 <= 120 * 1024) ? rowb5 : 0;         \
-			const bool small5 = INPUT == IN_2BIT && rowb5 <= 32 * 1024;                      \
-			if (l5 > 48 * 1024 && !h->spa5_attr_set[INPUT]) {                                \
-				HIPCHK(hipFuncSetAttribute((const void *)spa5_kernel<KK, INPUT, 0, 512>,     \
-					hipFuncAttributeMaxDynamicSharedMemorySize, (int)l5));                   \
-				HIPCHK(hipFuncSetAttribute((const void *)spa5_kernel<KK, INPUT, 1, 512>,     \
-					hipFuncAttributeMaxDynamicSharedMemorySize, (int)l5));                   \
-				h->spa5_attr_set[INPUT] = true;                                              \
-			}                                                                                \
-			const int fx5 = (h->force_exact ? 1 : 0) | (h->spa_abl & ~1);                    \
-			if (small5) {                                                                    \
-				/* (2-bit rows only: the constant keeps the other inputs' 128-thread forms uninstantiated) */ \
-				constexpr int IN5 = INPUT == IN_2BIT ? INPUT : IN_2BIT;                      \
-				hipLaunchKernelGGL((spa5_kernel<KK, IN5, 0, 128>), dim3((unsigned)h->nwg5), dim3(128), \
-					l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
-					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
-				hipLaunchKernelGGL((spa5_kernel<KK, IN5, 1, 128>), dim3((unsigned)h->nwg5), dim3(128), \
-					l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
-					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
-			} else {                                                                         \
-				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 0, 512>), dim3((unsigned)h->n_cu), dim3(512), \
-					l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
-					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
-				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 1, 512>), dim3((unsigned)h->n_cu), dim3(512), \
-					l5, st, rows, row_bytes, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
-					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
-			}                                                                                \
-			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rows,    \
-				row_bytes, md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
-				h->scratch_stride, out8);                                                    \
-		}                                                                                    \
-		break;
-			FOR_EACH_K(CASE)
-#undef CASE
-#undef MOMENTS
-		}
-		HIPCHK(hipGetLastError());
-		h->stats.spa_launches = (h->force_v1 && INPUT != IN_2BIT) ? 1u : (uint32_t)(4 * ((M + h->vcap4 - 1) / h->vcap4) + 3);
-	}
+	h->stats.score_launches = 1;
+	int rc = launch_spa<INPUT>(h, rr, M, out8);
+	if (rc) return rc;
 	HIPCHK(hipEventRecord(h->ev[2], st));
 	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 24 * sizeof(int), hipMemcpyDeviceToHost, st));
 	h->stats.n_variants = M;
@@ -770,7 +762,7 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 			sgx_handle *t = new sgx_handle();
 			t->device = h->device; t->md = h->md; t->mf_ok = h->mf_ok; t->mfe = h->mfe;
 			for (int g = 0; g < MF_MAXG; g++) { t->mf[g] = h->mf[g]; t->mf_nbfv[g] = h->mf_nbfv[g]; }
-			t->dF = h->dF; t->dX = h->dX; t->dy = h->dy; t->dmu = h->dmu; t->dmu2 = h->dmu2; t->dXM = h->dXM; t->dFl = h->dFl;
+			t->dF = h->dF; t->dX = h->dX; t->dy = h->dy; t->dmu = h->dmu; t->dmu2 = h->dmu2; t->dXM = h->dXM; t->dFl = h->dFl; t->dQ = h->dQ;
 			t->shares_model = true; t->owner = h;
 			t->force_dense = h->force_dense; t->force_v1 = h->force_v1; t->force_exact = h->force_exact;
 			rc = set_dev(t);
@@ -848,6 +840,268 @@ extern "C" int sgx_get_stats_total(sgx_handle *h, sgx_stats *st, uint64_t *n_cal
 	return SGX_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Genotype blocks (kern_score3.h)
+
+extern "C" size_t sgx_block_bytes(int32_t n_samp, size_t max_variants)
+{
+	if (n_samp <= 0 || max_variants == 0) return 0;
+	const int ntile = 2 * ((n_samp + 511) / 512);
+	const size_t lim = std::max<size_t>(64, (size_t)n_samp / 128);
+	return s3_block_bytes(max_variants, ntile) + max_variants * lim * 4 + max_variants * (S3_NR * 8 + 5) + 4;
+}
+
+extern "C" void sgx_block_free(sgx_block *b)
+{
+	if (!b) return;
+	(void)hipSetDevice(b->device);
+	(void)hipFree(b->tiles); (void)hipFree(b->cnt); (void)hipFree(b->ptr); (void)hipFree(b->idx);
+	(void)hipFree(b->n3); (void)hipFree(b->ovf);
+	delete b;
+}
+
+extern "C" int sgx_block_create(int32_t n_samp, size_t max_variants, int device, sgx_block **out)
+{
+	if (!out) return fail(SGX_EINVAL, "sgx_block_create: NULL argument");
+	*out = nullptr;
+	if (n_samp <= 0 || max_variants == 0 || max_variants > 0x7fffffffu / S3_NR)
+		return fail(SGX_EINVAL, "sgx_block_create: n_samp = %d, max_variants = %zu", n_samp, max_variants);
+	int ndev = 0;
+	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SGX_ENODEV, "sgx_block_create: no HIP device available");
+	if (device < 0 || device >= ndev) return fail(SGX_EINVAL, "sgx_block_create: device %d out of range", device);
+	sgx_block *b = new sgx_block();
+	b->device = device; b->N = n_samp; b->ntile = 2 * ((n_samp + 511) / 512); b->cap = max_variants;
+	// the list holds up to max(64, N / 128) missing genotypes per variant on average (0.8 % at large N);
+	// variants beyond a full list, or with more than 16 times that, take the FP64 kernel
+	b->idx_cap = std::min<size_t>(max_variants * std::max<size_t>(64, (size_t)n_samp / 128), 0xF0000000u);
+	hipError_t e = hipSetDevice(device);
+	if (e == hipSuccess) e = hipMalloc((void **)&b->tiles, s3_block_bytes(max_variants, b->ntile));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->cnt, (size_t)S3_NR * max_variants * sizeof(int));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->ptr, ((size_t)S3_NR * max_variants + 1) * sizeof(unsigned));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->idx, b->idx_cap * sizeof(unsigned));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->n3, max_variants * sizeof(int));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->ovf, max_variants);
+	if (e != hipSuccess) { sgx_block_free(b); return fail(e == hipErrorOutOfMemory ? SGX_ENOMEM : SGX_EHIP, "sgx_block_create: %s", hipGetErrorString(e)); }
+	*out = b;
+	return SGX_OK;
+}
+
+// rows [v_first, v_first + m) of the block from row-major device rows: tiles + counts (any number of
+// calls, v_first a multiple of 16), then block_finish once for the lists
+static int block_put_rows(sgx_block *b, const uint8_t *rows_dev, size_t bpv, size_t v_first, size_t m, hipStream_t st)
+{
+	const int nfrag = (int)((m + 15) / 16);
+	hipLaunchKernelGGL(s3_ingest_tile_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, rows_dev, bpv, b->N, (int)m, b->ntile,
+		b->tiles + (v_first / 16) * (size_t)b->ntile * 1024, b->cnt + v_first, b->cap);
+	HIPCHK(hipGetLastError());
+	return SGX_OK;
+}
+
+static int block_finish(sgx_block *b, size_t M, hipStream_t st)
+{
+	const size_t lim = 16 * std::max<size_t>(64, (size_t)b->N / 128);
+	hipLaunchKernelGGL(s3_ingest_scan_kernel, dim3(1), dim3(1024), 0, st, (int)M, b->cap, (int)std::min<size_t>(lim, 0x7fffffff), (unsigned)b->idx_cap,
+		b->cnt, b->n3, b->ovf, b->ptr);
+	const int nfrag = (int)((M + 15) / 16);
+	hipLaunchKernelGGL(s3_ingest_fill_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, b->tiles, (int)M, b->ntile, b->ovf, b->ptr, b->idx);
+	HIPCHK(hipGetLastError());
+	b->M = M;
+	return SGX_OK;
+}
+
+static int check_block_args(sgx_handle *h, sgx_block *b, size_t bpv, size_t M, const char *who)
+{
+	if (!h || !b) return fail(SGX_EINVAL, "%s: NULL argument", who);
+	if (b->device != h->device) return fail(SGX_EINVAL, "%s: block and handle are on different devices", who);
+	if (M == 0 || M > b->cap) return fail(SGX_EINVAL, "%s: %zu variants, the block holds up to %zu", who, M, b->cap);
+	if (bpv % 16 != 0 || bpv < (size_t)b->ntile * 64)
+		return fail(SGX_EINVAL, "Invalid length of dosages: bytes_per_variant=%zu, need a multiple of 16 >= %zu", bpv, (size_t)b->ntile * 64);
+	return SGX_OK;
+}
+
+extern "C" int sgx_block_load_dev(sgx_handle *h, sgx_block *b, const uint8_t *packed_dev, size_t bpv, size_t M)
+{
+	int rc = check_block_args(h, b, bpv, M, "sgx_block_load_dev");
+	if (rc) return rc;
+	if (!packed_dev || ((uintptr_t)packed_dev & 15u)) return fail(SGX_EINVAL, "sgx_block_load_dev: packed_dev must be a 16-byte aligned device pointer");
+	rc = set_dev(h);
+	if (rc) return rc;
+	rc = block_put_rows(b, packed_dev, bpv, 0, M, h->stream);
+	if (rc) return rc;
+	return block_finish(b, M, h->stream);
+}
+
+extern "C" size_t sgx_block_variants(const sgx_block *b) { return b ? b->M : 0; }
+
+// Per NBF the instantiation of score3_kernel: fragments per consumer wave, consumer / row-loader / B-loader
+// waves, tiles ahead (rows / B) -- what fits 160 KiB of LDS and the registers of that many waves, the
+// fastest of the forms measured with tools/score3_bench (tools/README.md).
+#define S3_FOR_EACH_NBF(X) \
+	X(2, 4, 8, 3, 1, 3, 2) X(3, 4, 8, 3, 1, 3, 1) X(4, 4, 8, 3, 1, 2, 2) X(5, 3, 8, 3, 1, 3, 1) X(6, 3, 8, 3, 1, 3, 1) \
+	X(7, 4, 4, 2, 2, 3, 1) X(8, 4, 4, 2, 2, 3, 1) X(9, 4, 4, 2, 2, 3, 1) X(10, 4, 4, 2, 2, 3, 1) X(11, 4, 4, 2, 2, 3, 1) \
+	X(12, 3, 4, 2, 2, 3, 1) X(13, 3, 4, 2, 2, 3, 1) X(14, 2, 4, 2, 2, 3, 1) X(15, 2, 4, 2, 2, 3, 1) X(16, 2, 4, 2, 2, 3, 1)
+
+template <typename T>
+static int ensure_buf(sgx_handle *h, T **p, size_t *cap, size_t need)
+{
+	if (need <= *cap) return SGX_OK;
+	HIPCHK(hipStreamSynchronize(h->stream));
+	if (*p) HIPCHK(hipFree(*p));
+	*p = nullptr; *cap = 0;
+	HIPCHK(hipMalloc((void **)p, need * sizeof(T)));
+	*cap = need;
+	return SGX_OK;
+}
+
+// Scan of a loaded block on this lane's stream: contraction, sparse pass over the missing genotypes, reduction,
+// epilogue, the FP64 kernel for what the lists do not cover, SPA stage.
+static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double *out8, uint8_t *valid)
+{
+	const DevModel &md = h->md;
+	const MfEpi &ep = h->mfe;
+	hipStream_t st = h->stream;
+	const int NBF = h->mf_nbfv[0] + 1;
+	const int grid = std::max(8, h->n_cu & ~7);
+	S3Plan pl{};
+	int NCW = 0, NAFW = 0;
+	HIPCHK(hipMemsetAsync(h->counters, 0, 24 * sizeof(int), st));
+	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 4 * sizeof(int), st));
+	HIPCHK(hipEventRecord(h->ev[0], st));
+	int rc = SGX_OK;
+	switch (NBF) {
+#define S3CASE(NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_)                                                        \
+	case NBF_: {                                                                                          \
+		NCW = NC_; NAFW = NAF_;                                                                           \
+		pl = s3_plan(M, b->ntile, grid, NAF_ * NC_);                                                      \
+		rc = ensure_buf(h, &h->s3_slabs, &h->s3_slabs_cap, (size_t)pl.ng * pl.ipg * NC_ * NAF_ * NBF_ * 256); \
+		if (rc) return rc;                                                                                \
+		const size_t lds = ((size_t)(DB_ + 1) * 4 * NBF_ + (size_t)(DA_ + 1) * NC_ * NAF_) * 1024;        \
+		auto kern = score3_kernel<NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_, 0>;                               \
+		if (!h->s3_attr[NBF_]) {                                                                          \
+			HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+			h->s3_attr[NBF_] = true;                                                                      \
+		}                                                                                                 \
+		hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (NC_ + NLA_ + NLB_)), lds, st,            \
+			(const uint8_t *)b->tiles, (const uint8_t *)h->dFl, pl, h->s3_slabs, (unsigned long long *)nullptr); \
+	} break;
+		S3_FOR_EACH_NBF(S3CASE)
+#undef S3CASE
+	default: return fail(SGX_EINVAL, "score3: %d B fragments not supported", NBF);
+	}
+	HIPCHK(hipGetLastError());
+	// sums over the missing samples
+	rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)S3_NR * M * md.P * 2);
+	if (rc) return rc;
+	rc = ensure_buf(h, &h->s3_ovf, &h->s3_ovf_cap, M);
+	if (rc) return rc;
+	{
+		const int PP = md.P <= 8 ? 8 : md.P <= 16 ? 16 : md.P <= 32 ? 32 : 64;
+		const int tpw = 64 / PP;
+		const unsigned chunks = (unsigned)((M + 4 * tpw - 1) / (4 * tpw));
+		const dim3 g3(chunks * S3_NR);
+		if (PP == 8) hipLaunchKernelGGL(s3_t3_kernel<8>, g3, dim3(256), 0, st, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
+		else if (PP == 16) hipLaunchKernelGGL(s3_t3_kernel<16>, g3, dim3(256), 0, st, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
+		else if (PP == 32) hipLaunchKernelGGL(s3_t3_kernel<32>, g3, dim3(256), 0, st, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
+		else hipLaunchKernelGGL(s3_t3_kernel<64>, g3, dim3(256), 0, st, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
+	}
+	{
+		const int per = NCW * NAFW * NBF * 256;
+		hipLaunchKernelGGL(s3_reduce_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)pl.vt), dim3(256), 0, st,
+			pl, (int)M, NCW, NAFW, NBF, h->s3_slabs, h->mf_acc, ep.acc_stride);
+	}
+	const int btop = md.quant ? 0 : (int)(2 * M);
+	switch (md.K) {
+#define ECASE(KK) case KK:                                                                     \
+	hipLaunchKernelGGL((score3_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, md, ep, h->mf_acc, \
+		h->s3_t3, b->n3, b->ovf, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid); \
+	hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, 256>), dim3((unsigned)std::min<size_t>(M, 4 * (size_t)h->n_cu)), dim3(256), 0, st, \
+		RowsRef{b->tiles, 0, b->ntile}, (int)M, md, h->recs, h->counters, out8, valid, (const int *)h->s3_ovf, 23, btop, h->fb_spa2, h->fb_x2); \
+	break;
+	FOR_EACH_K(ECASE)
+#undef ECASE
+	default: return fail(SGX_EINVAL, "score3: unsupported K=%d", md.K);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(h->ev[1], st));
+	h->stats.score_launches = 5;
+	rc = launch_spa<IN_2BIT>(h, RowsRef{b->tiles, 0, b->ntile}, M, out8);
+	if (rc) return rc;
+	HIPCHK(hipEventRecord(h->ev[2], st));
+	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 24 * sizeof(int), hipMemcpyDeviceToHost, st));
+	h->stats.n_variants = M;
+	h->stats_pending = true;
+	return SGX_OK;
+}
+
+// picks the lane of the next device-resident call (two lanes alternate) and makes it ready for M variants
+static int next_lane(sgx_handle *h, size_t M, sgx_handle **lane_out)
+{
+	sgx_handle *lane = h, *other = nullptr;
+	if (h->twin) {
+		lane = h->next_lane ? h->twin : h;
+		other = h->next_lane ? h : h->twin;
+		h->next_lane ^= 1;
+	}
+	int rc = sync_lane(lane);            // the lane's previous call is done: keep its stats (events are reused)
+	if (rc) return rc;
+	h->last_issued = lane;
+	rc = ensure_recs(lane, M);
+	if (rc) return rc;
+	// score stages do not overlap: this one starts after the other lane's has ended
+	if (other && other->stats_pending) HIPCHK(hipStreamWaitEvent(lane->stream, other->ev[1], 0));
+	*lane_out = lane;
+	return SGX_OK;
+}
+
+extern "C" int sgx_scan_block(sgx_handle *h, const sgx_block *b, double *out8_dev, uint8_t *valid_dev)
+{
+	if (!h || !b) return fail(SGX_EINVAL, "sgx_scan_block: NULL argument");
+	if (!out8_dev || !valid_dev) return fail(SGX_EINVAL, "sgx_scan_block: NULL buffer");
+	if (b->M == 0) return SGX_OK;
+	if (b->device != h->device) return fail(SGX_EINVAL, "sgx_scan_block: block and handle are on different devices");
+	if (b->N != h->md.N) return fail(SGX_EINVAL, "sgx_scan_block: the block holds rows of %d samples, the model has %d", b->N, h->md.N);
+	int rc = set_dev(h);
+	if (rc) return rc;
+	sgx_handle *lane = nullptr;
+	rc = next_lane(h, b->M, &lane);
+	if (rc) return rc;
+	if (!h->mf_ok || h->force_v1) {
+		// FP64 kernels on the tiled rows (test hook; models outside the fixed-point form's range)
+		hipStream_t st = lane->stream;
+		HIPCHK(hipMemsetAsync(lane->counters, 0, 24 * sizeof(int), st));
+		if (lane->cur5) HIPCHK(hipMemsetAsync(lane->cur5, 0, 4 * sizeof(int), st));
+		HIPCHK(hipEventRecord(lane->ev[0], st));
+		const RowsRef rr{b->tiles, 0, b->ntile};
+		switch (lane->md.K) {
+#define VCASE(KK) case KK: hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, 256>), dim3((unsigned)b->M), dim3(256), 0, st, rr, (int)b->M, lane->md, \
+	lane->recs, lane->counters, out8_dev, valid_dev, (const int *)nullptr, 0, 0, (int *)nullptr, (int *)nullptr); break;
+		FOR_EACH_K(VCASE)
+#undef VCASE
+		}
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(lane->ev[1], st));
+		lane->stats.score_launches = 1;
+		rc = launch_spa<IN_2BIT>(lane, rr, b->M, out8_dev);
+		if (rc) return rc;
+		HIPCHK(hipEventRecord(lane->ev[2], st));
+		HIPCHK(hipMemcpyAsync(lane->h_counters, lane->counters, 24 * sizeof(int), hipMemcpyDeviceToHost, st));
+		lane->stats.n_variants = b->M;
+		lane->stats_pending = true;
+		return SGX_OK;
+	}
+	return launch_block_scan(lane, b, b->M, out8_dev, valid_dev);
+}
+
+// a scratch block of this lane for calls that bring row-major rows
+static int ensure_tmp_block(sgx_handle *lane, int which, size_t M)
+{
+	sgx_block *&tb = lane->tmp_blk[which];
+	if (tb && tb->cap >= M) return SGX_OK;
+	HIPCHK(hipStreamSynchronize(lane->stream));
+	if (tb) { sgx_block_free(tb); tb = nullptr; }
+	return sgx_block_create(lane->md.N, M, lane->device, &tb);
+}
+
 extern "C" int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev, size_t bpv,
 	size_t M, double *out8_dev, uint8_t *valid_dev)
 {
@@ -855,7 +1109,7 @@ extern "C" int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev, size_
 	if (M == 0) return SGX_OK;
 	if (!packed_dev || !out8_dev || !valid_dev)
 		return fail(SGX_EINVAL, "sgx_scan_2bit_dev: NULL buffer");
-	if (M > 0x7fffffffu) return fail(SGX_EINVAL, "sgx_scan_2bit_dev: too many variants in one call");
+	if (M > 0x7fffffffu / S3_NR) return fail(SGX_EINVAL, "sgx_scan_2bit_dev: too many variants in one call");
 	if (bpv % 64 != 0 || bpv < sgx_row_stride(h->md.N))
 		return fail(SGX_EINVAL, "Invalid length of dosages: bytes_per_variant=%zu, need a multiple of 64 >= %zu",
 			bpv, sgx_row_stride(h->md.N));
@@ -863,20 +1117,17 @@ extern "C" int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev, size_
 		return fail(SGX_EINVAL, "sgx_scan_2bit_dev: packed_dev must be 16-byte aligned");
 	int rc = set_dev(h);
 	if (rc) return rc;
-	sgx_handle *lane = h, *other = nullptr;
-	if (h->twin) {
-		lane = h->next_lane ? h->twin : h;
-		other = h->next_lane ? h : h->twin;
-		h->next_lane ^= 1;
-	}
-	rc = sync_lane(lane);                // the lane's previous call is done: keep its stats (events are reused)
+	sgx_handle *lane = nullptr;
+	rc = next_lane(h, M, &lane);
 	if (rc) return rc;
-	h->last_issued = lane;
-	rc = ensure_recs(lane, M);
+	if (!h->mf_ok || h->force_v1) return launch_scan<IN_2BIT>(lane, packed_dev, bpv, M, out8_dev, valid_dev);
+	// the rows into this lane's scratch block, then the block scan
+	rc = ensure_tmp_block(lane, 0, M);
 	if (rc) return rc;
-	// score stages do not overlap: this one starts after the other lane's has ended
-	if (other && other->stats_pending) HIPCHK(hipStreamWaitEvent(lane->stream, other->ev[1], 0));
-	return launch_scan<IN_2BIT>(lane, packed_dev, bpv, M, out8_dev, valid_dev);
+	rc = block_put_rows(lane->tmp_blk[0], packed_dev, bpv, 0, M, lane->stream);
+	if (!rc) rc = block_finish(lane->tmp_blk[0], M, lane->stream);
+	if (rc) return rc;
+	return launch_block_scan(lane, lane->tmp_blk[0], M, out8_dev, valid_dev);
 }
 
 static const size_t STAGE_BYTES = (size_t)1 << 30;    // burden rows are made and scanned in chunks of this size
@@ -967,10 +1218,15 @@ static int scan_host(sgx_handle *h, const void *rows, size_t src_row_bytes, size
 	// a chunk's rows on the device: as they arrive (+ the doubles INTEGER rows may have to become)
 	const size_t per_row = dev_row_bytes + (INPUT == IN_I32 ? (size_t)N * sizeof(double) : 0);
 	size_t chunk = std::min(M, std::max<size_t>(1, (h->pipe_bytes ? h->pipe_bytes : PIPE_BYTES) / per_row));
-	rc = ensure_pipe(h, chunk * per_row, can_pack ? chunk * pk_row : 0, chunk);
+	if (can_pack) chunk = std::min<size_t>(chunk, 65535);       // pack_rows_2bit: grid.y = rows
+	const size_t f64_off = (chunk * dev_row_bytes + 15) & ~(size_t)15;   // INTEGER rows that are not hard calls: their doubles
+	rc = ensure_pipe(h, f64_off + (INPUT == IN_I32 ? chunk * (size_t)N * sizeof(double) : 0), can_pack ? chunk * pk_row : 0, chunk);
 	if (rc) return rc;
 	rc = ensure_recs(h, chunk);
 	if (rc) return rc;
+	// 2-bit rows (as they come, or packed from hard calls) go through a scratch block per pipeline buffer
+	const bool blocks = (INPUT == IN_2BIT || can_pack) && h->mf_ok && !h->force_v1;
+	if (blocks) for (int b = 0; b < 2; b++) { rc = ensure_tmp_block(h, b, chunk); if (rc) return rc; }
 	sgx_stats total{};
 	auto harvest = [&](size_t off, size_t m, int b) -> int {       // chunk [off, off + m) of buffer b is done
 		int r2 = sync_lane(h);
@@ -1015,17 +1271,26 @@ static int scan_host(sgx_handle *h, const void *rows, size_t src_row_bytes, size
 		}
 		double *as_f64 = nullptr;
 		if (INPUT == IN_I32 && !packed_ok) {
-			as_f64 = reinterpret_cast<double *>(h->pipe_in[b] + chunk * dev_row_bytes);
+			as_f64 = reinterpret_cast<double *>(h->pipe_in[b] + f64_off);
 			hipLaunchKernelGGL(i32_rows_to_f64, dim3(1024), dim3(256), 0, h->cstream,
 				(const int *)h->pipe_in[b], m * (size_t)N, as_f64);
 			HIPCHK(hipGetLastError());
+		}
+		// the chunk's 2-bit rows into the buffer's block, still on the copy stream
+		const bool as_block = blocks && (INPUT == IN_2BIT || packed_ok);
+		if (as_block) {
+			const uint8_t *r2 = INPUT == IN_2BIT ? h->pipe_in[b] : h->pipe_pk[b];
+			rc = block_put_rows(h->tmp_blk[b], r2, INPUT == IN_2BIT ? dev_row_bytes : pk_row, 0, m, h->cstream);
+			if (!rc) rc = block_finish(h->tmp_blk[b], m, h->cstream);
+			if (rc) return rc;
 		}
 		HIPCHK(hipEventRecord(h->ev_h2d, h->cstream));
 		// ---- chunk i - 1 has been computing meanwhile: collect it
 		if (prev_m) { rc = harvest(prev_off, prev_m, b ^ 1); if (rc) return rc; }
 		// ---- compute chunk i, results to pinned memory
 		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_h2d, 0));
-		if (INPUT == IN_2BIT) rc = launch_scan<IN_2BIT>(h, h->pipe_in[b], dev_row_bytes, m, h->pipe_out[b], h->pipe_valid[b]);
+		if (as_block) rc = launch_block_scan(h, h->tmp_blk[b], m, h->pipe_out[b], h->pipe_valid[b]);
+		else if (INPUT == IN_2BIT) rc = launch_scan<IN_2BIT>(h, h->pipe_in[b], dev_row_bytes, m, h->pipe_out[b], h->pipe_valid[b]);
 		else if (packed_ok) rc = launch_scan<IN_2BIT>(h, h->pipe_pk[b], pk_row, m, h->pipe_out[b], h->pipe_valid[b]);
 		else if (INPUT == IN_U8) rc = launch_scan<IN_U8>(h, h->pipe_in[b], dev_row_bytes, m, h->pipe_out[b], h->pipe_valid[b]);
 		else if (INPUT == IN_I32) rc = launch_scan<IN_F64>(h, as_f64, (size_t)N * sizeof(double), m, h->pipe_out[b], h->pipe_valid[b]);
@@ -1056,6 +1321,52 @@ extern "C" void *sgx_host_alloc(size_t bytes)
 extern "C" void sgx_host_free(void *p)
 {
 	if (p) (void)hipHostFree(p);
+}
+
+// Rows in host memory into a block: chunks cross PCIe on the copy stream while the previous chunk is being
+// rearranged on the handle's stream; the lists are made once at the end.  Returns when the rows have left
+// the caller's buffer; the block is ready for sgx_scan_block on this handle (same stream).
+extern "C" int sgx_block_load(sgx_handle *h, sgx_block *b, const uint8_t *packed, size_t bpv, size_t M)
+{
+	if (!h || !b) return fail(SGX_EINVAL, "sgx_block_load: NULL argument");
+	if (!packed) return fail(SGX_EINVAL, "sgx_block_load: NULL buffer");
+	if (b->device != h->device) return fail(SGX_EINVAL, "sgx_block_load: block and handle are on different devices");
+	if (M == 0 || M > b->cap) return fail(SGX_EINVAL, "sgx_block_load: %zu variants, the block holds up to %zu", M, b->cap);
+	if (bpv < (size_t)(b->N + 3) / 4)
+		return fail(SGX_EINVAL, "Invalid length of dosages: bytes_per_variant=%zu < ceil(N/4)=%zu", bpv, (size_t)(b->N + 3) / 4);
+	int rc = set_dev(h);
+	if (rc) return rc;
+	const size_t dev_row = (size_t)b->ntile * 64;
+	size_t chunk = std::max<size_t>(16, ((h->pipe_bytes ? h->pipe_bytes : PIPE_BYTES) / dev_row) & ~(size_t)15);
+	chunk = std::min(chunk, (M + 15) & ~(size_t)15);
+	rc = ensure_pipe(h, chunk * dev_row, 0, 1);
+	if (rc) return rc;
+	hipEvent_t ev_copy[2], ev_done[2];
+	for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&ev_copy[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_done[k], hipEventDisableTiming)); }
+	int i = 0;
+	for (size_t off = 0; off < M; off += chunk, i++) {
+		const size_t m = std::min(chunk, M - off);
+		const int k = i & 1;
+		if (i >= 2) HIPCHK(hipStreamWaitEvent(h->cstream, ev_done[k], 0));      // the buffer's previous chunk has been rearranged
+		const uint8_t *src = packed + off * bpv;
+		if (bpv == dev_row) {
+			HIPCHK(hipMemcpyAsync(h->pipe_in[k], src, m * dev_row, hipMemcpyHostToDevice, h->cstream));
+		} else {
+			if (dev_row > bpv) HIPCHK(hipMemsetAsync(h->pipe_in[k], 0, m * dev_row, h->cstream));
+			HIPCHK(hipMemcpy2DAsync(h->pipe_in[k], dev_row, src, bpv, std::min(bpv, dev_row), m, hipMemcpyHostToDevice, h->cstream));
+		}
+		HIPCHK(hipEventRecord(ev_copy[k], h->cstream));
+		HIPCHK(hipStreamWaitEvent(h->stream, ev_copy[k], 0));
+		rc = block_put_rows(b, h->pipe_in[k], dev_row, off, m, h->stream);
+		if (rc) return rc;
+		HIPCHK(hipEventRecord(ev_done[k], h->stream));
+	}
+	rc = block_finish(b, M, h->stream);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(h->cstream));      // the caller's buffer is free
+	HIPCHK(hipStreamSynchronize(h->stream));
+	for (int k = 0; k < 2; k++) { (void)hipEventDestroy(ev_copy[k]); (void)hipEventDestroy(ev_done[k]); }
+	return SGX_OK;
 }
 
 extern "C" int sgx_scan_2bit(sgx_handle *h, const uint8_t *packed, size_t bpv, size_t M,

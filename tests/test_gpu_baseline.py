@@ -92,7 +92,7 @@ def test_baseline_c3_exact_path_agrees():
 
 
 def test_baseline_c3_thirteen_covariates():
-    """K = 13 at N = 430 000: three column groups through the score kernel, 1024-sample segments and the
+    """K = 13 at N = 430 000: eleven B fragments in one pass of the score kernel, 1024-sample segments and the
     8-wave form of the cumulant pass (420 segments), against the oracle."""
     from oracle import Oracle
     sm, sc, packed, bpv = _baseline_case(430_000, "binary", 0.01, 800, k=13)
@@ -101,7 +101,7 @@ def test_baseline_c3_thirteen_covariates():
         limbs, ngroups = sc.score_layout()
     finally:
         sc.close()
-    assert ngroups >= 3, (limbs, ngroups)
+    assert ngroups == 1 and int(limbs.sum()) + 1 > 8 * 16, (limbs, ngroups)      # one pass, more than 8 value fragments
     ref, ref_valid = Oracle(sm).scan_2bit(packed.cpu().numpy())
     assert_table_close(out, valid, ref, ref_valid, what="C3 K=13")
     assert tot["n_spa"] > 20, tot
