@@ -5,9 +5,11 @@
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one pass of the hot path (score stage + SPA stage, through
-sgx_scan_2bit_dev) over one block of 50 000 variants (the reference's
-seqParallel block size, R/assoc_single.r:204) of synthetic 2-bit genotypes that
-are already resident in this GPU's HBM.  Every step scans a different block.
+sgx_scan_block) over one block of 50 000 variants (the reference's seqParallel
+block size, R/assoc_single.r:204) of synthetic 2-bit genotypes that are already
+resident in this GPU's HBM as genotype blocks (the library's device layout:
+what sgx_block_load leaves there when a block arrives from the GDS file).
+Every step scans a different block.
 
 Workloads; variants shard across ranks, per-GPU work is
 fixed (weak scaling); with 8 GPUs and 25 steps the job is BASELINE config [2]:
@@ -95,7 +97,7 @@ def main():
     import torch
     import torch.distributed as dist
     from saigegds_amd import synth
-    from saigegds_amd._lib import Scanner
+    from saigegds_amd._lib import Block, Scanner
     from saigegds_amd.nullmod import init_nullmod
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,18 +135,25 @@ def main():
 
     # ---- HBM-resident genotype pool --------------------------------------
     want = steps + warmup
-    pool = max(1, min(want, int(args.pool_gb * 1e9 // (block * bpv))))
-    packed = torch.empty((pool, block, bpv), dtype=torch.uint8, device=dev)
+    blk_bytes = Block.nbytes(n, block)
+    pool = max(1, min(want, int(args.pool_gb * 1e9 // blk_bytes)))
+    rows = torch.empty((block, bpv), dtype=torch.uint8, device=dev)       # one block of row-major rows: the generator's output
+    blocks = [Block(n, block, device=local) for _ in range(pool)]
     out = torch.empty((pool, block, 8), dtype=torch.float64, device=dev)
     valid = torch.empty((pool, block), dtype=torch.uint8, device=dev)
     t_gen = time.time()
+    t_load = 0.0
     for b in range(pool):
         first = (rank * pool + b) * block
         thr = synth.variant_thresholds(first, block, args.seed)
         thr_d = torch.from_numpy(thr.view(np.int32)).to(dev)
         torch.cuda.synchronize()
-        sc.synth_2bit_dev(packed[b].data_ptr(), bpv, block, first, args.seed, thr_d.data_ptr())
+        sc.synth_2bit_dev(rows.data_ptr(), bpv, block, first, args.seed, thr_d.data_ptr())
         sc.sync()
+        t = time.perf_counter()
+        sc.load_block_dev(blocks[b], rows.data_ptr(), bpv, block)       # rows -> tiles + lists of the missing genotypes
+        sc.sync()
+        t_load += time.perf_counter() - t
     t_gen = time.time() - t_gen
 
     lanes = args.lanes if pool >= 2 else 1     # two steps in flight need two result buffers
@@ -154,7 +163,7 @@ def main():
         # asynchronous: the library queues the step on one of its streams (alternating with two
         # lanes); its HIP-event stage times are collected after the timed region
         b = i % pool
-        sc.scan_2bit_dev(packed[b].data_ptr(), bpv, block, out[b].data_ptr(), valid[b].data_ptr())
+        sc.scan_block(blocks[b], out[b].data_ptr(), valid[b].data_ptr())
 
     def barrier():
         torch.cuda.synchronize()
@@ -211,7 +220,7 @@ def main():
     # The kernel that streams the algorithmic bytes is score_mfma_kernel (one launch per column group;
     # K <= 3: one).  The SPA stage (spa4_moments + spa4_solve + spa5_kernel) re-reads only the rows
     # of the flagged variants; it is FP64-bound, not HBM-bound, and is reported as a stage beside it.
-    score_kernel = "score_mfma_kernel"
+    score_kernel = "score3_kernel"
     achieved = alg_bytes / (ms_score * 1e-3) / 1e9
     # HBM traffic from the PMC counters: only from a profile of THIS configuration (profiles/README.md)
     traffic, spa_traffic = None, None
@@ -256,13 +265,19 @@ def main():
         from oracle import Oracle
         b0 = warmup % pool
         cores, cpu_model = _physical_cores()
-        pilot = packed[b0, :64].cpu().numpy()
+        # the same rows, regenerated row-major for the oracle
+        first0 = (rank * pool + b0) * block
+        thr_d = torch.from_numpy(synth.variant_thresholds(first0, block, args.seed).view(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        sc.synth_2bit_dev(rows.data_ptr(), bpv, block, first0, args.seed, thr_d.data_ptr())
+        sc.sync()
+        pilot = rows[:64].cpu().numpy()
         orc0 = Oracle(sm)
         t = time.perf_counter()
         orc0.scan_2bit(pilot)
         per = (time.perf_counter() - t) / 64
         ns = int(max(64 * cores, min(block, cores * args.cpu_seconds / max(per, 1e-9))))
-        sample = packed[b0, :ns].cpu().numpy()
+        sample = rows[:ns].cpu().numpy()
         bounds = np.linspace(0, ns, cores + 1).astype(int)
         workers = [Oracle(sm) for _ in range(cores)]         # ctypes calls release the GIL
 
@@ -322,8 +337,13 @@ def main():
         nh = min(block, args.host_variants)
         b0 = warmup % pool
         sc.set_option("lanes", 1)
+        first0 = (rank * pool + b0) * block
+        thr_d = torch.from_numpy(synth.variant_thresholds(first0, block, args.seed).view(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        sc.synth_2bit_dev(rows.data_ptr(), bpv, block, first0, args.seed, thr_d.data_ptr())
+        sc.sync()
         with PinnedBuffer((nh, bpv)) as pin:
-            pin.array[:] = packed[b0, :nh].cpu().numpy()
+            pin.array[:] = rows[:nh].cpu().numpy()
             sc.scan_2bit(pin.array[:1000])
             best = float("inf")
             for _ in range(2):
@@ -352,6 +372,8 @@ def main():
                 "resident_blocks": pool, "sharding": f"variants x{world}", "lanes": lanes,
                 "frac_spa": round(n_spa / max(1, nv_tot), 5), "frac_valid": round(n_valid / max(1, nv_tot), 5),
                 "gen_seconds": round(t_gen, 2),
+                "block_load_ms": round(t_load / pool * 1e3, 2),
+                "block_bytes": blk_bytes,
             },
             "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path,
         }

@@ -128,7 +128,7 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 		// ---------------------------------------------------------------- loaders
 		const bool rows = wid < NC + NLA;
 		const int l = __builtin_amdgcn_readfirstlane(rows ? wid - NC : wid - NC - NLA);
-		const int voff = lane * 16;
+		const int voff = (rows ? s3_dma_lane(lane) : lane) * 16;   // rows: LDS slot `lane` receives the KiB's slot of (variant r, piece kg)
 		Pos pa = pc;
 		int sl = 0;                                           // slot of the next tile to issue
 		int ahead = 0;                                        // tiles issued beyond the one the next barrier releases
@@ -342,7 +342,7 @@ s3_ingest_tile_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int M
 	const int r = lane & 15, kg = lane >> 4, v = frag * 16 + r;
 	const bool live = v < M;
 	const uint8_t *src = rows + (size_t)(live ? v : 0) * bpv + kg * 16;
-	uint8_t *dst = tiles + (size_t)frag * ntile * 1024 + lane * 16;
+	uint8_t *dst = tiles + (size_t)frag * ntile * 1024 + s3_dma_lane(lane) * 16;
 	constexpr int UN = 4;
 	int rg = 0, tend = s3_range_t0(1, ntile), c = 0;
 	for (int t0 = 0; t0 < ntile; t0 += UN) {
@@ -450,7 +450,7 @@ s3_ingest_fill_kernel(const uint8_t *__restrict__ tiles, int M, int ntile, const
 	if (frag >= nfrag) return;
 	const int r = lane & 15, kg = lane >> 4, v = frag * 16 + r;
 	const bool live = v < M && !ovf[v];
-	const uint8_t *src = tiles + (size_t)frag * ntile * 1024 + lane * 16;
+	const uint8_t *src = tiles + (size_t)frag * ntile * 1024 + s3_dma_lane(lane) * 16;
 	constexpr int UN = 4;
 	int rg = -1, tend = 0;
 	unsigned off = 0;
@@ -501,6 +501,7 @@ s3_t3_kernel(int M, int P, const long long *__restrict__ Q, const unsigned *__re
 	long long *__restrict__ part)
 {
 	constexpr int TPW = 64 / PP;                       // tasks per wave
+	constexpr int NB = PP <= 16 ? 4 : 2;               // index loads in flight per lane: NB x PP gathers behind them
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 	const int g = blockIdx.x % S3_NR, chunk = blockIdx.x / S3_NR;
 	const int c = lane % PP, tk = lane / PP;
@@ -509,22 +510,37 @@ s3_t3_kernel(int M, int P, const long long *__restrict__ Q, const unsigned *__re
 	if (v < M) { e0 = ptr[(size_t)g * M + v]; e1 = ptr[(size_t)g * M + v + 1]; }
 	long long hi = 0, lo = 0;
 	const int gbase = lane - c;                        // first lane of this task
-	for (unsigned e = e0; __any(e < e1); e += PP) {
-		const unsigned mine = (e + c < e1) ? idx[e + c] : 0xFFFFFFFFu;
+	for (unsigned e = e0; __any(e < e1); e += NB * PP) {
+		unsigned mine[NB];
 #pragma unroll
-		for (int j = 0; j < PP; j++) {
-			const unsigned s = (unsigned)__shfl((int)mine, gbase + j, 64);
-			if (s != 0xFFFFFFFFu && c < P) {
-				const long long q = Q[(size_t)s * P + c];
-				hi += q >> 32;
-				lo += q & 0xFFFFFFFFll;
+		for (int k = 0; k < NB; k++) mine[k] = (e + k * PP + c < e1) ? idx[e + k * PP + c] : 0xFFFFFFFFu;
+		long long q[NB * PP];
+#pragma unroll
+		for (int k = 0; k < NB; k++)
+#pragma unroll
+			for (int j = 0; j < PP; j++) {
+				const unsigned s = (unsigned)__shfl((int)mine[k], gbase + j, 64);
+				q[k * PP + j] = (s != 0xFFFFFFFFu && c < P) ? Q[(size_t)s * P + c] : 0;
 			}
-		}
+#pragma unroll
+		for (int k = 0; k < NB * PP; k++) { hi += q[k] >> 32; lo += q[k] & 0xFFFFFFFFll; }
 	}
 	if (v < M && c < P) {
 		long long *o = part + (((size_t)g * M + v) * P + c) * 2;
 		o[0] = hi; o[1] = lo;
 	}
+}
+
+// sums of the per-range partials: t3[v][c] = {hi, lo}
+__global__ void __launch_bounds__(256)
+s3_t3_sum_kernel(size_t n, const long long *__restrict__ part, long long *__restrict__ t3)
+{
+	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // over M x P x 2
+	if (i >= n) return;
+	long long s = 0;
+#pragma unroll
+	for (int g = 0; g < S3_NR; g++) s += part[(size_t)g * n + i];
+	t3[i] = s;
 }
 
 // ---- the item slabs of score3_kernel -> one row of limb sums per variant (the layout the epilogue reads:
@@ -552,7 +568,7 @@ s3_reduce_kernel(S3Plan pl, int M, int NCW, int NAF, int NBF, const int *__restr
 // missing genotypes are not listed go onto `ovf_list` (counters[23]) for the FP64 kernel.
 template <int K>
 __global__ void __launch_bounds__(256)
-score3_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf, const long long *__restrict__ t3part,
+score3_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf, const long long *__restrict__ t3part /* [M][P][2] totals */,
 	const int *__restrict__ n3buf, const uint8_t *__restrict__ ovf, int *__restrict__ ovf_list,
 	SpaRec *__restrict__ recs, int *__restrict__ counters, int btop, int *__restrict__ fb_series, int *__restrict__ fb_exact,
 	double *__restrict__ out8, uint8_t *__restrict__ valid)
@@ -571,14 +587,7 @@ score3_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf, co
 	double *o = out8 + (size_t)j * 8;
 	if (!h.pass) { nan_row(o); valid[j] = 0; return; }
 	const double imp = 2 * h.AF;
-	auto t3_of = [&](int c) -> HiLo {
-		long long hi = 0, lo = 0;
-		for (int g = 0; g < S3_NR; g++) {
-			const long long *p = t3part + (((size_t)g * M + j) * P + c) * 2;
-			hi += p[0]; lo += p[1];
-		}
-		return hl(hi, lo);
-	};
+	auto t3_of = [&](int c) -> HiLo { const long long *p = t3part + ((size_t)j * P + c) * 2; return hl(p[0], p[1]); };
 	double acc[P];
 	HiLo Wm = hl(0, 0), T3m = hl(0, 0);
 #pragma unroll

@@ -64,11 +64,15 @@ __host__ __device__ __forceinline__ void s3_items_of(const S3Plan &p, int vtile,
 // bytes of one tiled block of M variants: nfrag fragments x ntile KiB
 static inline size_t s3_block_bytes(size_t M, int ntile) { return ((M + 15) / 16) * (size_t)ntile * 1024; }
 
-// byte offset of the 16-B piece p (64 samples) of variant j in the tiled layout
+// byte offset of the 16-B piece p (64 samples) of variant j in the tiled layout: inside the KiB of (fragment,
+// tile) the 64 bytes of a variant are contiguous, so whoever reads ONE row (the SPA kernels) touches whole
+// 64-byte sectors; the contraction kernel's loader permutes the lanes of its DMA instead (s3_dma_lane)
 __host__ __device__ __forceinline__ size_t s3_piece_off(size_t j, size_t p, int ntile)
 {
-	return ((j >> 4) * (size_t)ntile + (p >> 2)) * 1024 + (((p & 3) << 4) + (j & 15)) * 16;
+	return ((j >> 4) * (size_t)ntile + (p >> 2)) * 1024 + (((j & 15) << 2) + (p & 3)) * 16;
 }
+// 16-byte slot of the KiB that the consumer lane (r = lane & 15: variant, kg = lane >> 4: 64-sample piece) wants
+__host__ __device__ __forceinline__ int s3_dma_lane(int lane) { return ((lane & 15) << 2) | (lane >> 4); }
 
 // Sample order inside a group of 16 (as kern_score_mfma.h mf_pos): byte j of (w >> 2t) & 0x03030303 is
 // the code of sample 4 j + t, and the B tiles store the 16 samples of a group in that order.

@@ -990,7 +990,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	}
 	HIPCHK(hipGetLastError());
 	// sums over the missing samples
-	rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)S3_NR * M * md.P * 2);
+	rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)(S3_NR + 1) * M * md.P * 2);      // per-range partials, then the totals
 	if (rc) return rc;
 	rc = ensure_buf(h, &h->s3_ovf, &h->s3_ovf_cap, M);
 	if (rc) return rc;
@@ -1003,6 +1003,8 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 		else if (PP == 16) hipLaunchKernelGGL(s3_t3_kernel<16>, g3, dim3(256), 0, st, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
 		else if (PP == 32) hipLaunchKernelGGL(s3_t3_kernel<32>, g3, dim3(256), 0, st, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
 		else hipLaunchKernelGGL(s3_t3_kernel<64>, g3, dim3(256), 0, st, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
+		const size_t n3e = M * (size_t)md.P * 2;
+		hipLaunchKernelGGL(s3_t3_sum_kernel, dim3((unsigned)((n3e + 255) / 256)), dim3(256), 0, st, n3e, h->s3_t3, h->s3_t3 + (size_t)S3_NR * n3e);
 	}
 	{
 		const int per = NCW * NAFW * NBF * 256;
@@ -1013,7 +1015,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	switch (md.K) {
 #define ECASE(KK) case KK:                                                                     \
 	hipLaunchKernelGGL((score3_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, md, ep, h->mf_acc, \
-		h->s3_t3, b->n3, b->ovf, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid); \
+		h->s3_t3 + (size_t)S3_NR * M * md.P * 2, b->n3, b->ovf, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid); \
 	hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, 256>), dim3((unsigned)std::min<size_t>(M, 4 * (size_t)h->n_cu)), dim3(256), 0, st, \
 		RowsRef{b->tiles, 0, b->ntile}, (int)M, md, h->recs, h->counters, out8, valid, (const int *)h->s3_ovf, 23, btop, h->fb_spa2, h->fb_x2); \
 	break;
@@ -1023,7 +1025,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[1], st));
-	h->stats.score_launches = 5;
+	h->stats.score_launches = 6;
 	rc = launch_spa<IN_2BIT>(h, RowsRef{b->tiles, 0, b->ntile}, M, out8);
 	if (rc) return rc;
 	HIPCHK(hipEventRecord(h->ev[2], st));
