@@ -496,12 +496,12 @@ s3_ingest_fill_kernel(const uint8_t *__restrict__ tiles, int M, int ntile, const
 // on one range (blockIdx % S3_NR): with blocks dealt round-robin over the XCDs an L2 sees two ranges of Q
 // (1/8 of the table).  part: [S3_NR][M][P][2] int64.
 template <int PP>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, PP <= 16 ? 8 : 4)    /* K <= 7: few enough registers to sit beside score3_kernel's workgroup on a CU */
 s3_t3_kernel(int M, int P, const long long *__restrict__ Q, const unsigned *__restrict__ ptr, const unsigned *__restrict__ idx,
 	long long *__restrict__ part)
 {
 	constexpr int TPW = 64 / PP;                       // tasks per wave
-	constexpr int NB = PP <= 16 ? 4 : 2;               // index loads in flight per lane: NB x PP gathers behind them
+	constexpr int NB = 1;                              // index loads in flight per lane: NB x PP gathers behind them
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 	const int g = blockIdx.x % S3_NR, chunk = blockIdx.x / S3_NR;
 	const int c = lane % PP, tk = lane / PP;
@@ -514,16 +514,20 @@ s3_t3_kernel(int M, int P, const long long *__restrict__ Q, const unsigned *__re
 		unsigned mine[NB];
 #pragma unroll
 		for (int k = 0; k < NB; k++) mine[k] = (e + k * PP + c < e1) ? idx[e + k * PP + c] : 0xFFFFFFFFu;
-		long long q[NB * PP];
+		constexpr int UN = 8;                          // gathers issued back to back (PP is a multiple of 8)
 #pragma unroll
 		for (int k = 0; k < NB; k++)
 #pragma unroll
-			for (int j = 0; j < PP; j++) {
-				const unsigned s = (unsigned)__shfl((int)mine[k], gbase + j, 64);
-				q[k * PP + j] = (s != 0xFFFFFFFFu && c < P) ? Q[(size_t)s * P + c] : 0;
-			}
+			for (int j0 = 0; j0 < PP; j0 += UN) {
+				long long q[UN];
 #pragma unroll
-		for (int k = 0; k < NB * PP; k++) { hi += q[k] >> 32; lo += q[k] & 0xFFFFFFFFll; }
+				for (int j = 0; j < UN; j++) {
+					const unsigned s = (unsigned)__shfl((int)mine[k], gbase + j0 + j, 64);
+					q[j] = (s != 0xFFFFFFFFu && c < P) ? Q[(size_t)s * P + c] : 0;
+				}
+#pragma unroll
+				for (int j = 0; j < UN; j++) { hi += q[j] >> 32; lo += q[j] & 0xFFFFFFFFll; }
+			}
 	}
 	if (v < M && c < P) {
 		long long *o = part + (((size_t)g * M + v) * P + c) * 2;

@@ -86,6 +86,7 @@ struct sgx_block {
 	size_t idx_cap = 0;
 	int *n3 = nullptr;           // [cap] missing genotypes per variant (listed or not)
 	uint8_t *ovf = nullptr;      // [cap] 1 = not listed (too many): the scan takes the FP64 kernel for it
+	hipEvent_t ready = nullptr;  // recorded behind the last load: scans on other streams wait for it
 };
 
 struct sgx_handle {
@@ -121,6 +122,8 @@ struct sgx_handle {
 	long long *s3_t3 = nullptr; size_t s3_t3_cap = 0;
 	int *s3_ovf = nullptr; size_t s3_ovf_cap = 0;
 	bool s3_attr[17] = {false};       // per NBF: dynamic LDS size raised
+	hipStream_t s3_side = nullptr;    // the sparse pass over the missing genotypes runs beside the contraction kernel
+	hipEvent_t s3_fork = nullptr, s3_join = nullptr;
 	sgx_block *tmp_blk[2] = {nullptr, nullptr};   // row-major calls: the rows are ingested into a block first
 	int n_cu = 256;
 	int *counters = nullptr;          // [0] n_spa, [1] n_valid, [2] n_fallback
@@ -274,6 +277,9 @@ static int alloc_workspace(sgx_handle *h)
 {
 	const int N = h->md.N;
 	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+	HIPCHK(hipStreamCreateWithFlags(&h->s3_side, hipStreamNonBlocking));
+	HIPCHK(hipEventCreateWithFlags(&h->s3_fork, hipEventDisableTiming));
+	HIPCHK(hipEventCreateWithFlags(&h->s3_join, hipEventDisableTiming));
 	HIPCHK(hipMalloc((void **)&h->counters, 24 * sizeof(int)));
 	HIPCHK(hipHostMalloc((void **)&h->h_counters, 24 * sizeof(int), hipHostMallocDefault));
 	for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&h->ev[i]));
@@ -519,6 +525,9 @@ extern "C" void sgx_free(sgx_handle *h)
 	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid); (void)hipFree(h->stage_pk); (void)hipFree(h->ds_part);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
 	for (int i = 0; i < 3; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+	if (h->s3_side) { (void)hipStreamSynchronize(h->s3_side); (void)hipStreamDestroy(h->s3_side); }
+	if (h->s3_fork) (void)hipEventDestroy(h->s3_fork);
+	if (h->s3_join) (void)hipEventDestroy(h->s3_join);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
 	delete h;
 }
@@ -857,6 +866,7 @@ extern "C" void sgx_block_free(sgx_block *b)
 	(void)hipSetDevice(b->device);
 	(void)hipFree(b->tiles); (void)hipFree(b->cnt); (void)hipFree(b->ptr); (void)hipFree(b->idx);
 	(void)hipFree(b->n3); (void)hipFree(b->ovf);
+	if (b->ready) (void)hipEventDestroy(b->ready);
 	delete b;
 }
 
@@ -881,6 +891,7 @@ extern "C" int sgx_block_create(int32_t n_samp, size_t max_variants, int device,
 	if (e == hipSuccess) e = hipMalloc((void **)&b->idx, b->idx_cap * sizeof(unsigned));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->n3, max_variants * sizeof(int));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->ovf, max_variants);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ready, hipEventDisableTiming);
 	if (e != hipSuccess) { sgx_block_free(b); return fail(e == hipErrorOutOfMemory ? SGX_ENOMEM : SGX_EHIP, "sgx_block_create: %s", hipGetErrorString(e)); }
 	*out = b;
 	return SGX_OK;
@@ -905,6 +916,7 @@ static int block_finish(sgx_block *b, size_t M, hipStream_t st)
 	const int nfrag = (int)((M + 15) / 16);
 	hipLaunchKernelGGL(s3_ingest_fill_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, b->tiles, (int)M, b->ntile, b->ovf, b->ptr, b->idx);
 	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(b->ready, st));
 	b->M = M;
 	return SGX_OK;
 }
@@ -946,6 +958,7 @@ static int ensure_buf(sgx_handle *h, T **p, size_t *cap, size_t need)
 {
 	if (need <= *cap) return SGX_OK;
 	HIPCHK(hipStreamSynchronize(h->stream));
+	if (h->s3_side) HIPCHK(hipStreamSynchronize(h->s3_side));
 	if (*p) HIPCHK(hipFree(*p));
 	*p = nullptr; *cap = 0;
 	HIPCHK(hipMalloc((void **)p, need * sizeof(T)));
@@ -964,10 +977,33 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	const int grid = std::max(8, h->n_cu & ~7);
 	S3Plan pl{};
 	int NCW = 0, NAFW = 0;
+	HIPCHK(hipStreamWaitEvent(st, b->ready, 0));
 	HIPCHK(hipMemsetAsync(h->counters, 0, 24 * sizeof(int), st));
 	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 4 * sizeof(int), st));
 	HIPCHK(hipEventRecord(h->ev[0], st));
-	int rc = SGX_OK;
+	int rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)(S3_NR + 1) * M * md.P * 2);      // per-range partials, then the totals
+	if (rc) return rc;
+	rc = ensure_buf(h, &h->s3_ovf, &h->s3_ovf_cap, M);
+	if (rc) return rc;
+	// sums over the missing samples, on the side stream: a pass bound by L2 latency whose workgroups fit
+	// beside the contraction kernel's (K <= 7), so it costs the step nothing
+	HIPCHK(hipEventRecord(h->s3_fork, st));
+	HIPCHK(hipStreamWaitEvent(h->s3_side, h->s3_fork, 0));
+	{
+		hipStream_t s2 = h->s3_side;
+		const int PP = md.P <= 8 ? 8 : md.P <= 16 ? 16 : md.P <= 32 ? 32 : 64;
+		const int tpw = 64 / PP;
+		const unsigned chunks = (unsigned)((M + 4 * tpw - 1) / (4 * tpw));
+		const dim3 g3(chunks * S3_NR);
+		if (PP == 8) hipLaunchKernelGGL(s3_t3_kernel<8>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
+		else if (PP == 16) hipLaunchKernelGGL(s3_t3_kernel<16>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
+		else if (PP == 32) hipLaunchKernelGGL(s3_t3_kernel<32>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
+		else hipLaunchKernelGGL(s3_t3_kernel<64>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
+		const size_t n3e = M * (size_t)md.P * 2;
+		hipLaunchKernelGGL(s3_t3_sum_kernel, dim3((unsigned)((n3e + 255) / 256)), dim3(256), 0, s2, n3e, h->s3_t3, h->s3_t3 + (size_t)S3_NR * n3e);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(h->s3_join, s2));
+	}
 	switch (NBF) {
 #define S3CASE(NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_)                                                        \
 	case NBF_: {                                                                                          \
@@ -989,28 +1025,12 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	default: return fail(SGX_EINVAL, "score3: %d B fragments not supported", NBF);
 	}
 	HIPCHK(hipGetLastError());
-	// sums over the missing samples
-	rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)(S3_NR + 1) * M * md.P * 2);      // per-range partials, then the totals
-	if (rc) return rc;
-	rc = ensure_buf(h, &h->s3_ovf, &h->s3_ovf_cap, M);
-	if (rc) return rc;
-	{
-		const int PP = md.P <= 8 ? 8 : md.P <= 16 ? 16 : md.P <= 32 ? 32 : 64;
-		const int tpw = 64 / PP;
-		const unsigned chunks = (unsigned)((M + 4 * tpw - 1) / (4 * tpw));
-		const dim3 g3(chunks * S3_NR);
-		if (PP == 8) hipLaunchKernelGGL(s3_t3_kernel<8>, g3, dim3(256), 0, st, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
-		else if (PP == 16) hipLaunchKernelGGL(s3_t3_kernel<16>, g3, dim3(256), 0, st, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
-		else if (PP == 32) hipLaunchKernelGGL(s3_t3_kernel<32>, g3, dim3(256), 0, st, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
-		else hipLaunchKernelGGL(s3_t3_kernel<64>, g3, dim3(256), 0, st, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
-		const size_t n3e = M * (size_t)md.P * 2;
-		hipLaunchKernelGGL(s3_t3_sum_kernel, dim3((unsigned)((n3e + 255) / 256)), dim3(256), 0, st, n3e, h->s3_t3, h->s3_t3 + (size_t)S3_NR * n3e);
-	}
 	{
 		const int per = NCW * NAFW * NBF * 256;
 		hipLaunchKernelGGL(s3_reduce_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)pl.vt), dim3(256), 0, st,
 			pl, (int)M, NCW, NAFW, NBF, h->s3_slabs, h->mf_acc, ep.acc_stride);
 	}
+	HIPCHK(hipStreamWaitEvent(st, h->s3_join, 0));
 	const int btop = md.quant ? 0 : (int)(2 * M);
 	switch (md.K) {
 #define ECASE(KK) case KK:                                                                     \
