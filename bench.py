@@ -29,7 +29,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+# MI355X_MICROARCH.md: HBM3E 8.0 TB/s peak (6.3 TB/s measured copy); 256 CUs x 4 SIMDs at 2.4 GHz;
+# v_mfma_i32_16x16x64_i8 16 cycles per SIMD, holding the SIMD's vector issue for 8 of them; every other
+# vector instruction 4 issue cycles
+HBM_PEAK_GBS = 8000.0
+CLOCK_HZ = 2.4e9
+MFMA_CYCLES, MFMA_ISSUE, VALU_ISSUE = 16, 8, 4
+UNPACK_OPS = 9              # vector instructions per (16 variants x 16 samples) dword of score3_kernel (kern_score3.h)
+BOUND_NAME = {"hbm": "hbm", "mfma": "mfma", "valu_issue": "valu issue"}
 
 WORKLOADS = {
     "c3": dict(n=430_000, trait="binary", prevalence=0.01, desc="configs[2] shard"),
@@ -76,6 +83,138 @@ def _physical_cores():
     return max(1, n), model
 
 
+class Case:
+    """One configuration resident on this rank's GPU: model, scanner, a pool of loaded genotype blocks."""
+
+    def __init__(self, workload, k, block, seed, pool_gb, want_blocks, rank, local, n_override=0):
+        import torch
+        from saigegds_amd import synth
+        from saigegds_amd._lib import Block, Scanner
+        from saigegds_amd.nullmod import init_nullmod
+        self.torch, self.synth = torch, synth
+        self.wl = dict(WORKLOADS[workload])
+        if n_override:
+            self.wl["n"] = n_override
+        self.workload, self.k, self.block, self.seed, self.rank = workload, k, block, seed, rank
+        self.n = n = self.wl["n"]
+        self.dev = torch.device("cuda", local)
+        mod = synth.synth_null_model(n, self.wl["trait"], self.wl["prevalence"], n_cov=k, seed=seed)
+        self.sm = init_nullmod(mod, np.arange(n), float("nan"), 10.0, 0.1, 0.05, float(mod.var_ratio[0]))
+        self.sc = Scanner(self.sm, device=local)
+        self.bpv = self.sc.row_stride()
+        self.blk_bytes = Block.nbytes(n, block)
+        self.pool = max(1, min(want_blocks, int(pool_gb * 1e9 // self.blk_bytes)))
+        # one block of row-major rows: the generator's output, rearranged into each block of the pool
+        self.rows = torch.empty((block, self.bpv), dtype=torch.uint8, device=self.dev)
+        self.blocks = [Block(n, block, device=local) for _ in range(self.pool)]
+        self.out = torch.empty((self.pool, block, 8), dtype=torch.float64, device=self.dev)
+        self.valid = torch.empty((self.pool, block), dtype=torch.uint8, device=self.dev)
+        t0 = time.time()
+        self.t_load = 0.0
+        for b in range(self.pool):
+            self.generate_rows(b)
+            t = time.perf_counter()
+            self.sc.load_block_dev(self.blocks[b], self.rows.data_ptr(), self.bpv, block)   # rows -> tiles + lists of the missing genotypes
+            self.sc.sync()
+            self.t_load += time.perf_counter() - t
+        self.t_gen = time.time() - t0
+        limbs, ngroups = self.sc.score_layout()
+        self.limbs = [int(x) for x in limbs]
+        self.nbf = (sum(self.limbs) + 1 + 15) // 16 + 1 if ngroups else 0      # B fragments of the score kernel (value + bit-1)
+
+    def generate_rows(self, b):
+        """the row-major rows of pool block b into self.rows (counter-based generator: any block, any time)"""
+        torch = self.torch
+        first = (self.rank * self.pool + b) * self.block
+        thr_d = torch.from_numpy(self.synth.variant_thresholds(first, self.block, self.seed).view(np.int32)).to(self.dev)
+        torch.cuda.synchronize()
+        self.sc.synth_2bit_dev(self.rows.data_ptr(), self.bpv, self.block, first, self.seed, thr_d.data_ptr())
+        self.sc.sync()
+
+    def step(self, i):
+        # asynchronous: the library queues the step on one of its streams (alternating with two lanes);
+        # its HIP-event stage times are collected after the timed region
+        b = i % self.pool
+        self.sc.scan_block(self.blocks[b], self.out[b].data_ptr(), self.valid[b].data_ptr())
+
+    def close(self):
+        for b in self.blocks:
+            b.close()
+        self.sc.close()
+
+    def bounds(self, n_cu=256):
+        """(algorithmic bytes per launch, the three rooflines of score3_kernel for this configuration)"""
+        nfrag, ntile = (self.block + 15) // 16, 2 * ((self.n + 511) // 512)
+        row_bytes = math.ceil(self.n / 4)
+        alg = self.block * (row_bytes + 64)                       # SURVEY 8(d): ceil(N/4) + 64 B per variant
+        dwords = nfrag * ntile * 4                                # (16 variants x 16 samples) units
+        n_mfma = dwords * self.nbf
+        n_valu = dwords * UNPACK_OPS
+        simd_hz = n_cu * 4 * CLOCK_HZ
+        return alg, {
+            "hbm_ms": round(alg / (HBM_PEAK_GBS * 1e9) * 1e3, 4),
+            "mfma_ms": round(n_mfma * MFMA_CYCLES / simd_hz * 1e3, 4),
+            "valu_issue_ms": round((n_valu * VALU_ISSUE + n_mfma * MFMA_ISSUE) / simd_hz * 1e3, 4),
+            "mfma_per_launch": n_mfma, "valu_per_launch": n_valu, "b_fragments": self.nbf,
+            "rates": "8 TB/s; v_mfma_i32_16x16x64_i8 16 cycles per SIMD (8 of them holding the vector issue port), "
+                     "other vector instructions 4 issue cycles; 1024 SIMDs at 2.4 GHz (MI355X_MICROARCH.md)",
+        }
+
+
+def measure(case, steps, warmup, lanes, world=1, dist=None, rehearse=False):
+    """warmup + K timed steps -> dict(elapsed, stage stats ...); the collective exchange is inside the timed region"""
+    torch = case.torch
+    sc = case.sc
+    lanes = lanes if case.pool >= 2 else 1            # two steps in flight need two result buffers
+    sc.set_option("lanes", lanes)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(warmup):
+        case.step(i)
+    sc.stats_total(reset=True)      # syncs; drops the warm-up steps from the sums
+    gathered, used = None, None
+    if world > 1:
+        # rank 0's receive buffers exist (and are touched) before the clock starts
+        used = sorted({(warmup + i) % case.pool for i in range(steps)})
+        shape = (len(used) * case.block, 8)
+        if case.rank == 0:
+            gathered = [torch.zeros(shape, dtype=torch.float64, device="cpu" if rehearse else case.dev) for _ in range(world)]
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        case.step(warmup + i)
+    sc.sync()
+    if world > 1:
+        # the path's one exchange step: result table to rank 0 (SURVEY 8(e))
+        tab = case.out[used].reshape(-1, 8)
+        if rehearse:
+            tab = tab.cpu()
+        dist.gather(tab, gathered, dst=0)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else case.dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    tot, ncalls = sc.stats_total(reset=True)
+    assert ncalls == steps, (ncalls, steps)
+    # the stages with nothing running beside them (one lane, a few extra steps outside the timed region)
+    iso = None
+    if lanes > 1:
+        sc.set_option("lanes", 1)
+        for i in range(min(3, case.pool)):
+            case.step(i)
+        ti, ni = sc.stats_total(reset=True)
+        iso = (ti["ms_score"] / ni, ti["ms_spa"] / ni)
+        sc.set_option("lanes", lanes)
+    return dict(elapsed=elapsed, tot=tot, iso=iso, lanes=lanes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,13 +231,12 @@ def main():
                     help="variants of one block pushed through the host-buffer entry point (PCIe-inclusive rate); 0 = skip")
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
                     help="library streams per GPU: with 2 the SPA stage of one step runs under the score stage of the next")
+    ap.add_argument("--secondary", type=int, default=1,
+                    help="1: after the main measurement (rank 0, one GPU) a few steps of K = 13, c2 and c4 into `secondary`")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from saigegds_amd import synth
-    from saigegds_amd._lib import Block, Scanner
-    from saigegds_amd.nullmod import init_nullmod
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -115,140 +253,78 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    rccl_ranks = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+        # one rank per GPU: every rank must sit on a device of its own
+        mine = torch.tensor([torch.cuda.current_device()], dtype=torch.int64, device="cpu" if rehearse else dev)
+        allv = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allv, mine)
+        devs = [int(x.item()) for x in allv]
+        if not rehearse and len(set(devs)) != world:
+            raise SystemExit(f"bench.py --gpus {world}: ranks share devices {devs}; launch one rank per GPU (LOCAL_RANK)")
+        rccl_ranks = {"backend": "gloo (rehearsal on one device)" if rehearse else "nccl (RCCL)",
+                      "world_size": dist.get_world_size(), "devices": devs}
 
-    wl = dict(WORKLOADS[args.workload])
-    if args.n_samp:
-        wl["n"] = args.n_samp
-    n, block, steps, warmup = wl["n"], args.block, args.steps, args.warmup
-
-    # ---- model (identical on every rank) --------------------------------
-    mod = synth.synth_null_model(n, wl["trait"], wl["prevalence"], n_cov=args.k, seed=args.seed)
-    sm = init_nullmod(mod, np.arange(n), float("nan"), 10.0, 0.1, 0.05, float(mod.var_ratio[0]))
-    sc = Scanner(sm, device=local)
-    bpv = sc.row_stride()
-
-    # ---- HBM-resident genotype pool --------------------------------------
-    want = steps + warmup
-    blk_bytes = Block.nbytes(n, block)
-    pool = max(1, min(want, int(args.pool_gb * 1e9 // blk_bytes)))
-    rows = torch.empty((block, bpv), dtype=torch.uint8, device=dev)       # one block of row-major rows: the generator's output
-    blocks = [Block(n, block, device=local) for _ in range(pool)]
-    out = torch.empty((pool, block, 8), dtype=torch.float64, device=dev)
-    valid = torch.empty((pool, block), dtype=torch.uint8, device=dev)
-    t_gen = time.time()
-    t_load = 0.0
-    for b in range(pool):
-        first = (rank * pool + b) * block
-        thr = synth.variant_thresholds(first, block, args.seed)
-        thr_d = torch.from_numpy(thr.view(np.int32)).to(dev)
-        torch.cuda.synchronize()
-        sc.synth_2bit_dev(rows.data_ptr(), bpv, block, first, args.seed, thr_d.data_ptr())
-        sc.sync()
-        t = time.perf_counter()
-        sc.load_block_dev(blocks[b], rows.data_ptr(), bpv, block)       # rows -> tiles + lists of the missing genotypes
-        sc.sync()
-        t_load += time.perf_counter() - t
-    t_gen = time.time() - t_gen
-
-    lanes = args.lanes if pool >= 2 else 1     # two steps in flight need two result buffers
-    sc.set_option("lanes", lanes)
-
-    def run_step(i):
-        # asynchronous: the library queues the step on one of its streams (alternating with two
-        # lanes); its HIP-event stage times are collected after the timed region
-        b = i % pool
-        sc.scan_block(blocks[b], out[b].data_ptr(), valid[b].data_ptr())
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(warmup):
-        run_step(i)
-    sc.stats_total(reset=True)      # syncs; drops the warm-up steps from the sums
-
-    # ---- timed region -------------------------------------------------------
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        run_step(warmup + i)
-    sc.sync()
-    if world > 1:
-        # the path's one exchange step: result table to rank 0
-        used = sorted({(warmup + i) % pool for i in range(steps)})
-        tab = out[used].reshape(-1, 8)
-        if rehearse:
-            tab = tab.cpu()
-        gathered = [torch.empty_like(tab) for _ in range(world)] if rank == 0 else None
-        dist.gather(tab, gathered, dst=0)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    block, steps, warmup = args.block, args.steps, args.warmup
+    case = Case(args.workload, args.k, block, args.seed, args.pool_gb, steps + warmup, rank, local, args.n_samp)
+    n, wl, sc, pool = case.n, case.wl, case.sc, case.pool
+    r = measure(case, steps, warmup, args.lanes, world, dist, rehearse)
+    elapsed, tot, lanes = r["elapsed"], r["tot"], r["lanes"]
 
     # ---- per-kernel figures (rank 0's launches) ----------------------------
-    # HIP events recorded by the library on ITS stream around the score stage
-    # (score_mfma_kernel + its 40 us epilogue) and around the SPA stage (spa4_moments / spa4_solve / spa5_kernel).
-    tot, ncalls = sc.stats_total(reset=True)
-    assert ncalls == steps, (ncalls, steps)
-    # the same kernel with nothing running beside it (one lane, a few extra steps outside the timed region)
-    iso_ms = None
-    if lanes > 1:
-        sc.set_option("lanes", 1)
-        for i in range(min(3, pool)):
-            run_step(i)
-        ti, ni = sc.stats_total(reset=True)
-        iso_ms = ti["ms_score"] / ni
-        sc.set_option("lanes", lanes)
+    # HIP events recorded by the library on ITS stream around the score stage (score3_kernel with the pass over
+    # the missing genotypes beside it on a side stream, then s3_reduce_kernel and score3_epilogue) and around
+    # the SPA stage (spa4_moments / spa4_solve / spa5_kernel).
     ms_score = tot["ms_score"] / steps
     ms_spa = tot["ms_spa"] / steps
     n_spa = int(tot["n_spa"])
     n_valid = int(tot["n_valid"])
     nv_tot = steps * block
     row_bytes = math.ceil(n / 4)
-    alg_bytes = block * (row_bytes + 64)             # ceil(N/4)+64 B per variant
-    # The kernel that streams the algorithmic bytes is score_mfma_kernel (one launch per column group;
-    # K <= 3: one).  The SPA stage (spa4_moments + spa4_solve + spa5_kernel) re-reads only the rows
-    # of the flagged variants; it is FP64-bound, not HBM-bound, and is reported as a stage beside it.
+    alg_bytes, bounds = case.bounds()
+    # The kernel that streams the algorithmic bytes is score3_kernel (ONE launch per step, any K).  The SPA
+    # stage re-reads only the rows of the flagged variants; it is FP64-issue-bound, not HBM-bound, and is
+    # reported as a stage beside it.
     score_kernel = "score3_kernel"
     achieved = alg_bytes / (ms_score * 1e-3) / 1e9
     # HBM traffic from the PMC counters: only from a profile of THIS configuration (profiles/README.md)
-    traffic, spa_traffic = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r02_pmc_stages.json")
+    traffic, spa_traffic, traffic_src = None, None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_stages.json")
     if os.path.exists(pmc_file):
         pm = json.load(open(pmc_file))
         if (pm.get("n_samples") == n and pm.get("variants_per_launch") == block and pm.get("n_covariates") == args.k
                 and pm.get("trait") == wl["trait"] and pm.get("workload") == args.workload):
             traffic = pm.get("score_hbm_bytes_per_launch")
             spa_traffic = pm.get("spa_hbm_bytes_per_step")
+            traffic_src = ("profiles/r03_pmc_stages.json: rocprofv3 --pmc passes of this configuration on another box of "
+                           "the pool (separate passes, gfx950 FETCH_SIZE correction); not measured in this run")
     spa_alg = n_spa / max(1, steps) * row_bytes      # rows of the flagged variants, read once more
     whole_gbs = alg_bytes * steps / elapsed / 1e9
+    binding = max(("hbm", "mfma", "valu_issue"), key=lambda b: bounds[b + "_ms"])
     roofline = {
-        "bound": "hbm", "kernel": score_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+        "bound": BOUND_NAME[binding], "kernel": score_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+        "bounds": bounds, "frac_of_binding": round(bounds[binding + "_ms"] / ms_score, 5),
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms_score, 4),
+        "launch_ms_note": "HIP events around the score stage on the library's stream: score3_kernel plus s3_reduce_kernel and "
+                          "score3_epilogue behind it (0.12 ms together at c3); the kernel alone: rocprofv3 summary under profiles/",
         "whole_step_frac": round(whole_gbs / HBM_PEAK_GBS, 5), "whole_step_gbs": round(whole_gbs, 2),
-        "alone": None if iso_ms is None else {
-            "avg_launch_ms": round(iso_ms, 4), "achieved": round(alg_bytes / (iso_ms * 1e-3) / 1e9, 2),
-            "frac": round(alg_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-            "note": "same kernel with one lane (no SPA stage of the previous step running beside it), 3 steps outside the timed region"},
+        "alone": None if r["iso"] is None else {
+            "avg_launch_ms": round(r["iso"][0], 4), "achieved": round(alg_bytes / (r["iso"][0] * 1e-3) / 1e9, 2),
+            "frac": round(alg_bytes / (r["iso"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "spa_stage_ms": round(r["iso"][1], 4),
+            "note": "one lane (no SPA stage of the previous step running beside it), 3 steps outside the timed region"},
         "stages": {
             "score": {"avg_ms": round(ms_score, 4), "launches_per_step": int(tot["score_launches"] // steps),
-                      "algorithmic_bytes": alg_bytes, "hbm_bytes": traffic, "bound": "hbm",
+                      "algorithmic_bytes": alg_bytes, "hbm_bytes": traffic, "bound": BOUND_NAME[binding],
                       "frac_of_hbm_peak": round(achieved / HBM_PEAK_GBS, 5)},
             "spa": {"avg_ms": round(ms_spa, 4), "launches_per_step": int(tot["spa_launches"] // steps),
                     "variants_per_step": n_spa / max(1, steps),
-                    "algorithmic_bytes": int(spa_alg), "hbm_bytes": spa_traffic, "bound": "fp64 valu",
+                    "algorithmic_bytes": int(spa_alg), "hbm_bytes": spa_traffic, "bound": "fp64 valu issue",
                     "exact_path_variants_per_step": int(tot["n_spa_slow"]) / max(1, steps),
                     "dense_fallback": int(tot["n_spa_dense"])},
             "note": "stage times are HIP events on the library's streams; with two lanes the stages of "
@@ -260,17 +336,13 @@ def main():
     # One oracle worker per physical core over the variants of one timed block (the reference's
     # seqParallel block, R/assoc_single.r:204), bounded by --cpu-seconds of wall time.
     cpu = None
+    b0 = warmup % pool
+    out, valid, rows, bpv, sm = case.out, case.valid, case.rows, case.bpv, case.sm
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import Oracle
-        b0 = warmup % pool
         cores, cpu_model = _physical_cores()
-        # the same rows, regenerated row-major for the oracle
-        first0 = (rank * pool + b0) * block
-        thr_d = torch.from_numpy(synth.variant_thresholds(first0, block, args.seed).view(np.int32)).to(dev)
-        torch.cuda.synchronize()
-        sc.synth_2bit_dev(rows.data_ptr(), bpv, block, first0, args.seed, thr_d.data_ptr())
-        sc.sync()
+        case.generate_rows(b0)            # the same rows, regenerated row-major for the oracle
         pilot = rows[:64].cpu().numpy()
         orc0 = Oracle(sm)
         t = time.perf_counter()
@@ -278,11 +350,11 @@ def main():
         per = (time.perf_counter() - t) / 64
         ns = int(max(64 * cores, min(block, cores * args.cpu_seconds / max(per, 1e-9))))
         sample = rows[:ns].cpu().numpy()
-        bounds = np.linspace(0, ns, cores + 1).astype(int)
+        bnd = np.linspace(0, ns, cores + 1).astype(int)
         workers = [Oracle(sm) for _ in range(cores)]         # ctypes calls release the GIL
 
         def job(i):
-            return workers[i].scan_2bit(sample[bounds[i]:bounds[i + 1]])
+            return workers[i].scan_2bit(sample[bnd[i]:bnd[i + 1]])
         t = time.perf_counter()
         with ThreadPoolExecutor(cores) as ex:
             parts = list(ex.map(job, range(cores)))
@@ -293,9 +365,9 @@ def main():
         ok = np.array_equal(got_valid, ref_valid)
         v = ref_valid.astype(bool)
         cols = [3, 4, 5] + ([] if sm.quant else [6])
-        a, r = got[v][:, cols], ref[v][:, cols]
+        a, rr = got[v][:, cols], ref[v][:, cols]
         with np.errstate(invalid="ignore", divide="ignore"):
-            rel = np.where(a == r, 0.0, np.abs(a - r) / np.abs(r))
+            rel = np.where(a == rr, 0.0, np.abs(a - rr) / np.abs(rr))
             # beta and SE: relative 1e-10 with an absolute floor of 1e-12 on the z-score
             # beta/SE (the score sum cancels to ~0 under the null; tests/conftest.py)
             zabs = np.abs(ref[v][:, 3]) / ref[v][:, 4]
@@ -335,13 +407,8 @@ def main():
     if rank == 0 and world == 1 and args.host_variants > 0:
         from saigegds_amd._lib import PinnedBuffer
         nh = min(block, args.host_variants)
-        b0 = warmup % pool
         sc.set_option("lanes", 1)
-        first0 = (rank * pool + b0) * block
-        thr_d = torch.from_numpy(synth.variant_thresholds(first0, block, args.seed).view(np.int32)).to(dev)
-        torch.cuda.synchronize()
-        sc.synth_2bit_dev(rows.data_ptr(), bpv, block, first0, args.seed, thr_d.data_ptr())
-        sc.sync()
+        case.generate_rows(b0)
         with PinnedBuffer((nh, bpv)) as pin:
             pin.array[:] = rows[:nh].cpu().numpy()
             sc.scan_2bit(pin.array[:1000])
@@ -353,9 +420,50 @@ def main():
             same = bool(np.array_equal(hv, valid[b0, :nh].cpu().numpy()) and
                         np.array_equal(np.nan_to_num(ho, nan=-7.0), np.nan_to_num(out[b0, :nh].cpu().numpy(), nan=-7.0)))
         pcie = 63.0     # GB/s, PCIe Gen5 x16 (MI355X_MICROARCH.md)
-        host_path = {"value": round(nh / best, 1), "unit": "variants/s", "entry": "sgx_scan_2bit (pinned host block in, table out)",
+        host_path = {"value": round(nh / best, 1), "unit": "variants/s",
+                     "entry": "sgx_scan_2bit (pinned host block in: H2D, rearranged into a block on the device, scanned; table out)",
                      "variants": nh, "GBps_host_to_result": round(nh * (bpv + 65) / best / 1e9, 2), "pcie_peak_GBps": pcie,
                      "frac_of_pcie": round(nh * (bpv + 65) / best / 1e9 / pcie, 4), "same_table_as_resident_scan": same}
+
+    config = {
+        "workload": f"{args.workload}: {wl['desc']}, N={n} samples x {block} variants/step/GPU, "
+                    f"{wl['trait']} trait" + (f" prevalence {wl['prevalence']}" if wl['trait'] == 'binary' else ""),
+        "n_samples": n, "variants_per_step_per_gpu": block, "n_covariates": args.k,
+        "maf_law": "10^U(-3.3,-0.3), 10% alt-major, missing 1e-3", "thresholds": "mac=10 missing=0.1 spa.pval=0.05",
+        "resident_blocks": pool, "sharding": f"variants x{world}", "lanes": lanes,
+        "frac_spa": round(n_spa / max(1, nv_tot), 5), "frac_valid": round(n_valid / max(1, nv_tot), 5),
+        "gen_seconds": round(case.t_gen, 2),
+        "resident_format": "genotype blocks (sgx_block: tiles of 16 variants x 256 samples + lists of the missing genotypes), "
+                           "made on the device from the 2-bit rows by sgx_block_load_dev before the timed region",
+        "block_load_ms": round(case.t_load / pool * 1e3, 2), "block_bytes": case.blk_bytes,
+        "score_limbs": case.limbs,
+    }
+    case.close()
+    del case, out, valid, rows
+    torch.cuda.empty_cache()
+
+    # ---- other configurations, a few steps each (rank 0, N=1 only) -----------------------------------
+    secondary = None
+    if rank == 0 and world == 1 and args.secondary and args.workload == "c3" and args.k == 3 and not args.n_samp:
+        secondary = {}
+        for name, w2, k2 in (("k13", "c3", 13), ("c2", "c2", 3), ("c4", "c4", 3)):
+            c2 = Case(w2, k2, block, args.seed, min(args.pool_gb, 24.0), 6, rank, local)
+            r2 = measure(c2, 12, 3, args.lanes)
+            alg2, b2 = c2.bounds()
+            ms2 = r2["tot"]["ms_score"] / 12
+            bind2 = max(("hbm", "mfma", "valu_issue"), key=lambda b: b2[b + "_ms"])
+            secondary[name] = {
+                "workload": f"{w2}, K={k2}, N={c2.n}", "value": round(12 * block / r2["elapsed"], 1), "unit": "variants/s",
+                "ms_per_step": round(r2["elapsed"] / 12 * 1e3, 3), "steps": 12,
+                "score_stage_ms": round(ms2, 4), "spa_stage_ms": round(r2["tot"]["ms_spa"] / 12, 4),
+                "frac": round(alg2 / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": BOUND_NAME[bind2],
+                "frac_of_binding": round(b2[bind2 + "_ms"] / ms2, 5),
+                "bounds": {k: b2[k] for k in ("hbm_ms", "mfma_ms", "valu_issue_ms", "b_fragments")},
+                "whole_step_frac": round(alg2 * 12 / r2["elapsed"] / 1e9 / HBM_PEAK_GBS, 5),
+            }
+            c2.close()
+            del c2
+            torch.cuda.empty_cache()
 
     if rank == 0:
         line = {
@@ -363,22 +471,15 @@ def main():
             "value": round(nv_tot * world / elapsed, 1), "unit": "variants/s",
             "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {
-                "workload": f"{args.workload}: {wl['desc']}, N={n} samples x {block} variants/step/GPU, "
-                            f"{wl['trait']} trait" + (f" prevalence {wl['prevalence']}" if wl['trait'] == 'binary' else ""),
-                "n_samples": n, "variants_per_step_per_gpu": block, "n_covariates": args.k,
-                "maf_law": "10^U(-3.3,-0.3), 10% alt-major, missing 1e-3", "thresholds": "mac=10 missing=0.1 spa.pval=0.05",
-                "resident_blocks": pool, "sharding": f"variants x{world}", "lanes": lanes,
-                "frac_spa": round(n_spa / max(1, nv_tot), 5), "frac_valid": round(n_valid / max(1, nv_tot), 5),
-                "gen_seconds": round(t_gen, 2),
-                "block_load_ms": round(t_load / pool * 1e3, 2),
-                "block_bytes": blk_bytes,
-            },
-            "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "dtype_note": "results are formed in FP64 from EXACT integer sums: the per-sample score vectors enter as 40/48/56-bit "
+                          "fixed point (int8 limbs on v_mfma_i32_16x16x64_i8, int32 accumulation), a quantisation below the rounding "
+                          "of the reference's own double sums (cpu_baseline.gpu_vs_longdouble_max_rel against oracle_vs_longdouble_max_rel)",
+            "data": "synthetic",
+            "config": config, "rccl_ranks": rccl_ranks,
+            "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path, "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
-    sc.close()
     if world > 1:
         dist.destroy_process_group()
 

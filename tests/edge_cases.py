@@ -64,8 +64,27 @@ def _candidates(rng, sm, count):
     return codes
 
 
+def degenerate(sm, codes_row):
+    """True when the (imputed, flipped) genotype vector lies in the span of the covariates: the residual
+    adj = G - X (X'VX)^-1 X'V G of saige_main.cpp:334-345 vanishes, var2 = sum mu2 adj^2 <= 1e-10 x
+    sum mu2 G^2.  Score and variance are then zero up to rounding and the reference's own beta, SE and
+    p-value are noise; what it still defines -- the filter, AF, mac, num, converged -- is compared."""
+    c = codes_row.astype(np.int64)
+    ok = c != 3
+    if not ok.any():
+        return True
+    af = c[ok].sum() / (2.0 * ok.sum())
+    g = np.where(ok, c, 2 * af).astype(np.float64)
+    if af > 0.5:
+        g = 2.0 - g
+    n, k = sm.n, sm.k
+    adj = g - sm.t_XXVX_inv.reshape(n, k) @ (sm.XV.reshape(n, k).T @ g)
+    return float(np.sum(sm.mu2 * adj * adj)) <= 1e-10 * float(np.sum(sm.mu2 * g * g))
+
+
 def build(per_kind=6, n_models=60, per_model=3000, seed=7):
-    """-> list of (ScanModel, packed [m, bpv], census dict) covering every kind in KINDS."""
+    """-> list of (ScanModel, packed [m, bpv], census dict, packed_degenerate [d, bpv]) covering every kind
+    in KINDS; the degenerate candidates of a model (see degenerate()) ride along apart."""
     from oracle import Oracle
     rng = np.random.default_rng(seed)
     found = {k: 0 for k in KINDS}
@@ -85,16 +104,20 @@ def build(per_kind=6, n_models=60, per_model=3000, seed=7):
             continue
         codes = _candidates(rng, sm, per_model)
         orc = Oracle(sm)
-        keep, census = [], {k: 0 for k in KINDS}
+        keep, degen, census = [], [], {k: 0 for k in KINDS}
         for r in range(per_model):
             before = orc.trace.as_dict()
             pk = pack_dosage_2bit(codes[r:r + 1])
             row, ok = orc.scan_2bit(pk)
             after = orc.trace.as_dict()
             hit = [k for k in KINDS if after[k] > before[k]]
-            # a genotype vector inside the span of the covariates (all heterozygous, say) has score
-            # and variance zero up to rounding: the reference's row is noise there, nothing to compare
-            if not ok[0] or not (1e-6 < abs(row[0, 3]) < 1e4 and np.isfinite(row[0, 4])):
+            if not ok[0]:
+                continue
+            # a genotype vector inside the span of the covariates (all heterozygous, say): only the
+            # filter and the counts are comparable (degenerate())
+            if degenerate(sm, codes[r]):
+                if len(degen) < 8:
+                    degen.append(r)
                 continue
             if any(found[k] < per_kind for k in hit):
                 keep.append(r)
@@ -105,7 +128,8 @@ def build(per_kind=6, n_models=60, per_model=3000, seed=7):
         if keep:
             # a few ordinary candidates ride along
             keep = sorted(set(keep) | set(range(0, per_model, per_model // 20)))
-            out.append((sm, pack_dosage_2bit(codes[keep]), census))
+            out.append((sm, pack_dosage_2bit(codes[keep]), census,
+                        pack_dosage_2bit(codes[degen]) if degen else np.zeros((0, (sm.n + 3) // 4), dtype=np.uint8)))
         if all(found[k] >= per_kind for k in KINDS):
             break
     return out, found
@@ -117,7 +141,8 @@ if __name__ == "__main__":
     cases, found = build()
     print(found, f"{len(cases)} models, {sum(c[1].shape[0] for c in cases)} variants, {time.time() - t:.1f} s")
     from oracle import Oracle
-    for sm, pk, census in cases:
+    print("degenerate candidates carried:", sum(c[3].shape[0] for c in cases))
+    for sm, pk, census, _ in cases:
         o = Oracle(sm)
         ref, valid = o.scan_2bit(pk)
         print(sm.n, pk.shape, census, o.trace.as_dict(), "p==0 fallback rows:",

@@ -175,6 +175,74 @@ def test_grm_crossprod_at_430k():
             assert np.max(np.abs(op.crossprod(b) - ref)) <= 1e-11 * np.max(np.abs(ref))
 
 
+def test_grm_pcg_at_430k():
+    """Config 5's solver at full sample count: sgx_grm_pcg (PCG_diag_sigma, src/saige_fitnull.cpp:581-614)
+    over 320 markers at N = 430 000 against grm_oracle.c -- binary-trait weights w = mu (1 - mu),
+    tau = (1, 0.33) as in saige_model.rds, the reference's tolPCG = 1e-5 / maxiterPCG = 500: same iteration
+    count, solution to 1e-8.  The vector kernels and block-partial dot products run at the benchmark size."""
+    from oracle import GrmOracle
+    from saigegds_amd import synth
+    from saigegds_amd._lib import GrmOperator
+    n, m = 430_000, 320
+    thr = synth.variant_thresholds(0, m, 11, log10_maf=(-2.0, -0.3), flip_frac=0.2, miss_rate=5e-3)
+    packed = synth.synth_packed(n, 0, m, 11, thr)
+    rng = np.random.default_rng(17)
+    mu = rng.uniform(0.002, 0.05, n)            # prevalence of config [2]
+    w = mu * (1 - mu)
+    b = rng.standard_normal(n)
+    orc = GrmOracle(packed, n)
+    with GrmOperator(packed, n) as op:
+        for tau in ([1.0, 0.33220629], [1.0, 0.0]):
+            xr, itr = orc.pcg(w, tau, b, 500, 1e-5)
+            xg, itg = op.pcg(w, tau, b, 500, 1e-5)
+            assert itg == itr and itr >= 1, (tau, itg, itr)
+            np.testing.assert_allclose(xg, xr, rtol=1e-8, atol=1e-10 * np.max(np.abs(xr)))
+
+
+def test_baseline_c3_one_call_of_50000_variants():
+    """One sgx_scan_block call over a whole block of 50 000 variants at N = 430 000 (the bench step): every
+    round of the score kernel's item list, all sixteen sample ranges of the missing-genotype lists, both
+    tiers of the SPA stage and the per-variant kernels in one launch sequence; 2 000 rows spread over the
+    block against the oracle."""
+    import torch
+    from oracle import Oracle
+    from saigegds_amd import synth
+    from saigegds_amd._lib import Block, Scanner
+    from saigegds_amd.nullmod import init_nullmod
+    n, m, seed = 430_000, 50_000, 20260
+    mod = synth.synth_null_model(n, "binary", 0.01, n_cov=3, seed=seed)
+    sm = init_nullmod(mod, np.arange(n), float("nan"), 10.0, 0.1, 0.05, float(mod.var_ratio[0]))
+    dev = torch.device("cuda", 0)
+    with Scanner(sm, device=0) as sc:
+        bpv = sc.row_stride()
+        rows = torch.empty((m, bpv), dtype=torch.uint8, device=dev)
+        thr = synth.variant_thresholds(0, m, seed)
+        thr_d = torch.from_numpy(thr.view(np.int32)).to(dev)
+        torch.cuda.synchronize()
+        sc.synth_2bit_dev(rows.data_ptr(), bpv, m, 0, seed, thr_d.data_ptr())
+        out = torch.empty((m, 8), dtype=torch.float64, device=dev)
+        valid = torch.empty(m, dtype=torch.uint8, device=dev)
+        with Block(n, m, device=0) as blk:
+            sc.load_block_dev(blk, rows.data_ptr(), bpv, m)
+            sc.scan_block(blk, out.data_ptr(), valid.data_ptr())
+            sc.sync()
+            st = sc.stats()
+            # the row-major entry point on the same rows gives the same table, bit for bit
+            out2 = torch.empty_like(out)
+            valid2 = torch.empty_like(valid)
+            sc.scan_2bit_dev(rows.data_ptr(), bpv, m, out2.data_ptr(), valid2.data_ptr())
+            sc.sync()
+        assert st["n_variants"] == m and st["n_spa"] > 1500
+        pick = np.unique(np.concatenate([np.arange(0, m, 25), np.arange(m - 40, m)]))
+        sample = rows[torch.from_numpy(pick).to(dev)].cpu().numpy()
+        got, got_valid = out.cpu().numpy(), valid.cpu().numpy()
+        assert np.array_equal(got_valid, valid2.cpu().numpy())
+        assert np.array_equal(np.nan_to_num(got, nan=-7.0), np.nan_to_num(out2.cpu().numpy(), nan=-7.0))
+    ref, ref_valid = Oracle(sm).scan_2bit(sample)
+    assert ref_valid.sum() > 1800
+    assert_table_close(got[pick], got_valid[pick], ref, ref_valid, what="C3, one call of 50 000 variants")
+
+
 def test_assoc_100snp_dosage_scan():
     """Config 1's second file: the dosages of assoc_100snp.gds (annotation/format/DS, dPackedReal8U;
     the file holds 0 / 1 / 2 only) through sgx_scan_f64 -- the REALSXP branch of get_ds
@@ -204,8 +272,8 @@ def test_root_finder_edge_branches():
     from saigegds_amd._lib import Scanner
     cases, found = build()
     assert all(found[k] >= 3 for k in KINDS), found
-    p0_rows = 0
-    for sm, packed, census in cases:
+    p0_rows = n_degen = 0
+    for sm, packed, census, packed_degen in cases:
         orc = Oracle(sm)
         ref, ref_valid = orc.scan_2bit(packed)
         tr = orc.trace.as_dict()
@@ -218,4 +286,16 @@ def test_root_finder_edge_branches():
             sc.set_option("spa_exact", 1)           # and the same rows through the exact kernels only
             out2, valid2 = sc.scan_2bit(packed)
             assert_table_close(out2, valid2, ref, ref_valid, what=f"edge branches (exact) N={sm.n}")
+            if packed_degen.shape[0]:
+                # genotype vectors inside the covariates' span: score and variance are rounding noise in the
+                # reference itself; the filter, the counts and (where the oracle's row is finite) the
+                # convergence flag are still defined and must agree
+                sc.set_option("spa_exact", 0)
+                refd, refd_valid = orc.scan_2bit(packed_degen)
+                outd, validd = sc.scan_2bit(packed_degen)
+                assert np.array_equal(validd, refd_valid), f"degenerate rows N={sm.n}: filter mask differs"
+                v = refd_valid.astype(bool)
+                assert np.array_equal(outd[v][:, :3], refd[v][:, :3]), f"degenerate rows N={sm.n}: AF/mac/num"
+                n_degen += int(v.sum())
     assert p0_rows >= 3
+    assert n_degen >= 1, "no degenerate candidate was carried"
