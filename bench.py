@@ -231,6 +231,8 @@ def main():
                     help="variants of one block pushed through the host-buffer entry point (PCIe-inclusive rate); 0 = skip")
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2],
                     help="library streams per GPU: with 2 the SPA stage of one step runs under the score stage of the next")
+    ap.add_argument("--file-variants", type=int, default=3000,
+                    help="variants written to a GDS file and scanned from it with seqAssocGLMM_SPA (file -> table rate); 0 = skip")
     ap.add_argument("--secondary", type=int, default=1,
                     help="1: after the main measurement (rank 0, one GPU) a few steps of K = 13, c2 and c4 into `secondary`")
     args = ap.parse_args()
@@ -425,6 +427,48 @@ def main():
                      "variants": nh, "GBps_host_to_result": round(nh * (bpv + 65) / best / 1e9, 2), "pcie_peak_GBps": pcie,
                      "frac_of_pcie": round(nh * (bpv + 65) / best / 1e9 / pcie, 4), "same_table_as_resident_scan": same}
 
+    # ---- file -> table: seqAssocGLMM_SPA on a GDS file (rank 0, N=1 only; never `value`) -----------------
+    from_file = None
+    if rank == 0 and world == 1 and args.file_variants > 0:
+        import tempfile
+        from saigegds_amd import assoc as assoc_mod
+        from saigegds_amd import synth as synth_mod
+        from saigegds_amd.gds_write import write_seqarray_genotypes
+        nf = min(block, args.file_variants)
+        case.generate_rows(b0)
+        host_rows = rows[:nf].cpu().numpy()
+        mod = synth_mod.synth_null_model(n, wl["trait"], wl["prevalence"], n_cov=args.k, seed=args.seed)
+        with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
+            fn = os.path.join(td, "bench_genotypes.gds")
+            t = time.perf_counter()
+            write_seqarray_genotypes(fn, host_rows[:, :(n + 3) // 4], n, sample_id=mod.sample_id, compress="none")
+            t_write = time.perf_counter() - t
+            fsize = os.path.getsize(fn)
+            old_bl = assoc_mod.BLOCK_SIZE
+            assoc_mod.BLOCK_SIZE = max(250, nf // 4)       # a few blocks, so that decoding runs ahead of scanning as it does over a whole file
+            try:
+                sc.set_option("lanes", 1)
+                tm = {}
+                t = time.perf_counter()
+                ans = assoc_mod.seqAssocGLMM_SPA(fn, mod, mac=10.0, missing=0.1, spa_pval=0.05,
+                                                 var_ratio=float(mod.var_ratio[0]), verbose=False, timing=tm)
+                t_scan = time.perf_counter() - t
+            finally:
+                assoc_mod.BLOCK_SIZE = old_bl
+        gv = valid[b0, :nf].cpu().numpy().astype(bool)
+        go = out[b0, :nf].cpu().numpy()[gv]
+        same = bool(len(ans["pval"]) == int(gv.sum()) and np.array_equal(np.asarray(ans["pval"]), go[:, 5])
+                    and np.array_equal(np.asarray(ans["beta"]), go[:, 3]) and np.array_equal(np.asarray(ans["AF.alt"]), go[:, 0]))
+        from_file = {"value": round(nf / t_scan, 1), "unit": "variants/s",
+                     "entry": "seqAssocGLMM_SPA(gdsfile, modobj): GDS file (genotype/data dBit2, stored uncompressed) -> result table, "
+                              "blocks decoded one ahead of the block being scanned",
+                     "variants": nf, "file_bytes": fsize, "seconds": round(t_scan, 3), "write_seconds": round(t_write, 2),
+                     "decode_MBps_of_file_bytes": round(fsize / max(tm.get("decode_s", 0.0), 1e-9) / 1e6, 1),
+                     "decode_seconds": round(tm.get("decode_s", 0.0), 3), "scan_seconds": round(tm.get("scan_s", 0.0), 3),
+                     "blocks": int(math.ceil(nf / max(250, nf // 4))), "same_table_as_resident_scan": same,
+                     "note": "the decoder (numpy, one thread per GPU) is the bound: two allele codes per sample are folded into "
+                             "2-bit dosage codes at the rate shown; the GPU side of the same rows is host_path"}
+
     config = {
         "workload": f"{args.workload}: {wl['desc']}, N={n} samples x {block} variants/step/GPU, "
                     f"{wl['trait']} trait" + (f" prevalence {wl['prevalence']}" if wl['trait'] == 'binary' else ""),
@@ -477,7 +521,7 @@ def main():
                           "of the reference's own double sums (cpu_baseline.gpu_vs_longdouble_max_rel against oracle_vs_longdouble_max_rel)",
             "data": "synthetic",
             "config": config, "rccl_ranks": rccl_ranks,
-            "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path, "secondary": secondary,
+            "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path, "from_file": from_file, "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

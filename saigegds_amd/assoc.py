@@ -77,7 +77,7 @@ def _is_num(x) -> bool:
 def seqAssocGLMM_SPA(gdsfile: Union[str, GdsFile, GenotypeSource], modobj: Any, maf: float = float("nan"),
                      mac: float = 10, missing: float = 0.1, dsnode: str = "", spa_pval: float = 0.05,
                      var_ratio: float = float("nan"), res_savefn: str = "", res_compress: str = "LZMA",
-                     parallel: Union[bool, int] = False, verbose: bool = True):
+                     parallel: Union[bool, int] = False, verbose: bool = True, timing: Optional[Dict[str, float]] = None):
     """SAIGE single-variant association scan on MI355X.
 
     Returns a ``dict`` of equal-length columns (``pandas.DataFrame(result)``
@@ -179,7 +179,7 @@ def seqAssocGLMM_SPA(gdsfile: Union[str, GdsFile, GenotypeSource], modobj: Any, 
     out = np.empty((n_var, 8), dtype=np.float64)
     valid = np.zeros(n_var, dtype=np.uint8)
     blocks = [(off, min(n_var, off + BLOCK_SIZE)) for off in range(0, n_var, BLOCK_SIZE)]
-    scan_blocks(lambda d: Scanner(mobj, device=d), ngpu, blocks, read_block, kind == "packed", out, valid)
+    scan_blocks(lambda d: Scanner(mobj, device=d), ngpu, blocks, read_block, kind == "packed", out, valid, timing)
 
     x = valid.astype(bool)           # R/assoc_single.r:225-234
     if verbose:
@@ -200,37 +200,64 @@ def seqAssocGLMM_SPA(gdsfile: Union[str, GdsFile, GenotypeSource], modobj: Any, 
     return ans
 
 
-def scan_blocks(make_scanner, ngpu: int, blocks, read_block, packed_rows: bool, out: np.ndarray, valid: np.ndarray):
+def scan_blocks(make_scanner, ngpu: int, blocks, read_block, packed_rows: bool, out: np.ndarray, valid: np.ndarray,
+                timing: Optional[Dict[str, float]] = None):
     """One host thread per GPU (the reference forks one SeqArray worker per core, seqParallel,
-    R/assoc_single.r:202-204): each thread owns a scanner, pulls the next block from a shared queue,
-    decodes it (lzma and numpy release the GIL) and scans it (the C ABI call releases the GIL), so the
-    GPUs work concurrently and a block's decode overlaps the other GPUs' scans."""
+    R/assoc_single.r:202-204): each thread owns a scanner and pulls blocks from a shared queue.  Every
+    scanner has a decoder thread of its own one block ahead of it: while block i crosses PCIe and is
+    scanned (the C ABI call releases the GIL), block i + 1 is being read and decoded (lzma / zlib and
+    numpy release the GIL), so neither the GPU nor the decoder waits for the other beyond the slower of
+    the two.  timing: seconds spent decoding / scanning (summed over threads) and decoded bytes."""
     import queue
     import threading
+    import time
+    from concurrent.futures import ThreadPoolExecutor
     todo: "queue.Queue" = queue.Queue()
     for b in blocks:
         todo.put(b)
     errors: List[BaseException] = []
+    tlock = threading.Lock()
+
+    def take():
+        try:
+            return todo.get_nowait()
+        except queue.Empty:
+            return None
+
+    def decode(rng):
+        t = time.perf_counter()
+        blk = read_block(*rng)
+        if timing is not None:
+            with tlock:
+                timing["decode_s"] = timing.get("decode_s", 0.0) + time.perf_counter() - t
+                timing["decoded_bytes"] = timing.get("decoded_bytes", 0.0) + blk.nbytes
+        return blk
 
     def worker(d: int):
         sc = None
         try:
             sc = make_scanner(d)
-            while not errors:
-                try:
-                    off, end = todo.get_nowait()
-                except queue.Empty:
-                    break
-                blk = read_block(off, end)
-                if packed_rows:
-                    o, v = sc.scan_2bit(blk)            # 2-bit packed rows
-                elif blk.dtype == np.uint8:
-                    o, v = sc.scan_u8(blk)
-                elif np.issubdtype(blk.dtype, np.integer):
-                    o, v = sc.scan_i32(blk)
-                else:
-                    o, v = sc.scan_f64(blk)
-                out[off:end], valid[off:end] = o, v
+            with ThreadPoolExecutor(1, thread_name_prefix=f"sgx-decode{d}") as ex:
+                rng = take()
+                fut = ex.submit(decode, rng) if rng is not None else None
+                while fut is not None and not errors:
+                    off, end = rng
+                    blk = fut.result()
+                    rng = take()                                       # the next block decodes while this one is scanned
+                    fut = ex.submit(decode, rng) if rng is not None else None
+                    t = time.perf_counter()
+                    if packed_rows:
+                        o, v = sc.scan_2bit(blk)            # 2-bit packed rows
+                    elif blk.dtype == np.uint8:
+                        o, v = sc.scan_u8(blk)
+                    elif np.issubdtype(blk.dtype, np.integer):
+                        o, v = sc.scan_i32(blk)
+                    else:
+                        o, v = sc.scan_f64(blk)
+                    out[off:end], valid[off:end] = o, v
+                    if timing is not None:
+                        with tlock:
+                            timing["scan_s"] = timing.get("scan_s", 0.0) + time.perf_counter() - t
         except BaseException as e:      # noqa: BLE001 -- re-raised in the caller's thread
             errors.append(e)
         finally:

@@ -7,8 +7,12 @@ single-variant scan consumes:
 
 * the directory tree (folder streams),
 * array nodes of class dBit2 (``genotype/data``), dInt32, dStr8/dStr16,
-  dFloat32/64, dPackedReal8[U] (``annotation/format/DS/data``),
-* stored uncompressed or as ``LZMA_RA`` (independent XZ blocks).
+  dFloat32/64, dPackedReal8[U] / dPackedReal16[U] (``annotation/format/DS/data``),
+* stored uncompressed, as one compressed stream (``LZMA``, ``ZIP``) or in gdsfmt's random-access
+  form: independent blocks behind an 18-byte header with a block index at the end (``LZMA_RA``:
+  XZ blocks, pinned by the reference's own files; ``ZIP_RA`` zlib and ``LZ4_RA`` LZ4 blocks in the
+  same framing -- no file of the reference uses them, so their framing is unpinned: the reader
+  accepts zlib / raw-deflate / gzip and LZ4 frame / raw LZ4 block payloads alike).
 
 Container layout (decoded from the files themselves):
   file   := "COREARRAYx0A" u8[2]version u32 root_id  block*
@@ -21,6 +25,7 @@ from __future__ import annotations
 import lzma
 import re
 import struct
+import zlib
 from typing import Dict, List, Optional, Tuple
 
 import numpy as np
@@ -84,6 +89,8 @@ class GdsFile:
         import threading
         self.buf = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
         self._tls = threading.local()
+        self._lock = threading.Lock()
+        self._whole: Dict[str, object] = {}      # decoded payload of the last node without random access
         if self.buf[:len(_MAGIC)] != _MAGIC:
             raise GdsError(f"{path}: not a CoreArray GDS file")
         self.root_id = struct.unpack_from("<I", self.buf, 14)[0]
@@ -140,14 +147,17 @@ class GdsFile:
                 break
         return b"".join(out)
 
+    _RA_MAGIC = {b"XZ_RA": "xz", b"ZIP_RA": "zip", b"LZ4_RA": "lz4"}
+
     def _ra_index(self, nd: "GdsNode"):
-        """Block table of an LZMA_RA stream: (stream offset, compressed size, raw offset, raw size).
-        Stream layout: "XZ_RA" u8[3] u32 nblk u48 index_offset(after the 18-byte header) xz-blocks
-        index[nblk] of (u24 compressed size, u32 raw size)."""
+        """Block table of a random-access stream: (stream offset, compressed size, raw offset, raw size).
+        Stream layout: magic + version (7 bytes: "XZ_RA" v v | "ZIP_RA" v | "LZ4_RA" v) u8 block-size code
+        u32 nblk u48 index_offset(after the 18-byte header) blocks index[nblk] of (u24 compressed size, u32 raw size)."""
         if getattr(nd, "_ra", None) is None:
             head = self.stream_read(nd.data_id, 0, 18)
-            if head[:5] != b"XZ_RA":
-                raise GdsError("bad LZMA_RA header")
+            kind = next((k for m, k in self._RA_MAGIC.items() if head.startswith(m)), None)
+            if kind is None:
+                raise GdsError("bad random-access stream header")
             nblk = struct.unpack_from("<I", head, 8)[0]
             ioff = _u48(head, 12) + 18
             idx = self.stream_read(nd.data_id, ioff, 7 * nblk)
@@ -158,7 +168,7 @@ class GdsFile:
                 tab.append((so, cs, ro, rs))
                 so += cs
                 ro += rs
-            nd._ra = tab
+            nd._ra, nd._ra_kind = tab, kind
         return nd._ra
 
     def raw_range(self, path: str, lo: int, hi: int) -> bytes:
@@ -169,17 +179,22 @@ class GdsFile:
         pipe = nd.pipe.upper()
         if pipe == "":
             return self.stream_read(nd.data_id, lo, hi - lo)
-        if not pipe.startswith("LZMA_RA"):
-            return self.raw(path)[lo:hi]              # one XZ stream: no random access
+        if not pipe.endswith("_RA") and "_RA:" not in pipe and "_RA" not in pipe:
+            # one compressed stream: no random access -- decode once per file object, not once per block
+            with self._lock:
+                if self._whole.get("path") != path:
+                    self._whole = {"path": path, "data": self.raw(path)}
+                return self._whole["data"][lo:hi]
         out = []
         cache = self._tls.__dict__.setdefault("ra", {})     # last decoded block per node, per thread
-        for k, (so, cs, ro, rs) in enumerate(self._ra_index(nd)):
+        tab = self._ra_index(nd)
+        for k, (so, cs, ro, rs) in enumerate(tab):
             if ro + rs <= lo or ro >= hi:
                 continue
             if cache.get(path, (-1, b""))[0] != k:
-                blk = lzma.LZMADecompressor(format=lzma.FORMAT_XZ).decompress(self.stream_read(nd.data_id, so, cs))
+                blk = _decode_block(nd._ra_kind, self.stream_read(nd.data_id, so, cs), rs)
                 if len(blk) != rs:
-                    raise GdsError("LZMA_RA block size mismatch")
+                    raise GdsError("random-access block size mismatch")
                 cache[path] = (k, blk)
             blk = cache[path][1]
             out.append(blk[max(lo, ro) - ro:min(hi, ro + rs) - ro])
@@ -190,12 +205,14 @@ class GdsFile:
         nd = self.node(path)
         cls, dims = nd.cls or "", tuple(nd.dims or ())
         width = {"dInt32": 4, "dUInt32": 4, "dInt8": 1, "dUInt8": 1, "dInt16": 2, "dUInt16": 2, "dFloat32": 4,
-                 "dFloat64": 8, "dPackedReal8U": 1, "dPackedReal8": 1}.get(cls)
+                 "dFloat64": 8, "dPackedReal8U": 1, "dPackedReal8": 1, "dPackedReal16U": 2, "dPackedReal16": 2}.get(cls)
         if width is None or not dims:
             raise GdsError(f"{path}: read_rows needs a fixed-width array, not {cls!r}")
         per = int(np.prod(dims[1:])) if len(dims) > 1 else 1
         data = self.raw_range(path, r0 * per * width, r1 * per * width)
         shape = (r1 - r0,) + dims[1:]
+        if cls in ("dPackedReal16U", "dPackedReal16"):
+            return _packed_real16(np.frombuffer(data, dtype="<u2"), cls, nd.scale, nd.offset).reshape(shape)
         if cls in ("dPackedReal8U", "dPackedReal8"):
             by = np.frombuffer(data, dtype=np.uint8)
             if cls == "dPackedReal8U":
@@ -284,8 +301,15 @@ class GdsFile:
         pipe = nd.pipe.upper()
         if pipe == "":
             return s
-        if pipe.startswith("LZMA_RA") or pipe.startswith("LZMA"):
-            return _decode_xz(s, ra=pipe.startswith("LZMA_RA"))
+        if "_RA" in pipe:
+            tab = self._ra_index(nd)
+            return b"".join(_decode_block(nd._ra_kind, s[so:so + cs], rs) for so, cs, _, rs in tab)
+        if pipe.startswith("LZMA"):
+            return _decode_xz(s, ra=False)
+        if pipe.startswith("ZIP"):
+            return _decode_block("zip", s, None)
+        if pipe.startswith("LZ4"):
+            return _decode_block("lz4", s, None)
         raise GdsError(f"{path}: unsupported compression {nd.pipe!r}")
 
     def read(self, path: str):
@@ -313,6 +337,8 @@ class GdsFile:
             for k in range(4):
                 v[:, k] = (by >> (2 * k)) & 3
             return v.reshape(-1)[:n].reshape(dims)
+        if cls in ("dPackedReal16U", "dPackedReal16"):
+            return _packed_real16(np.frombuffer(data, dtype="<u2", count=n), cls, nd.scale, nd.offset).reshape(dims)
         if cls in ("dPackedReal8U", "dPackedReal8"):
             by = np.frombuffer(data, dtype=np.uint8, count=n)
             if cls == "dPackedReal8U":
@@ -373,29 +399,59 @@ class GdsFile:
             cls._NIB = lut
         return cls._NIB
 
-    def dosage_alt_packed_range(self, v0: int, v1: int, sample_sel: Optional[np.ndarray] = None) -> np.ndarray:
+    def dosage_alt_packed_range(self, v0: int, v1: int, sample_sel: Optional[np.ndarray] = None,
+                                out: Optional[np.ndarray] = None, chunk_bytes: int = 64 << 20) -> np.ndarray:
         """``$dosage_alt`` of variants [v0, v1) as 2-bit codes, 4 samples per byte: code = number of
         non-reference alleles, 3 = missing (any allele missing).  ``sample_sel``: sample indices to
-        keep, in the order wanted.  Only the LZMA_RA blocks that hold the range are decoded."""
+        keep, in the order wanted.  ``out``: a [>= v1 - v0, >= ceil(n / 4)] uint8 buffer to fill (a
+        pinned block buffer, say; bytes beyond a row's codes are zeroed) -- else a new array.
+        Only the compressed blocks that hold the range are decoded, and the work is done in pieces of
+        about ``chunk_bytes`` of temporaries, whatever the block size: at N = 430 000 a block of 50 000
+        variants is 10.75 GB of allele codes, which never exist at once (the reference's seqApply works
+        variant by variant)."""
         M, N = self.genotype_dims()
         v0, v1 = max(0, v0), min(M, v1)
         m = v1 - v0
-        bits0, bits1 = v0 * N * 4, v1 * N * 4
-        data = np.frombuffer(self.raw_range("genotype/data", bits0 // 8, (bits1 + 7) // 8), dtype=np.uint8)
-        if N % 2 == 0 and sample_sel is None:
-            nib = self._nibble_lut()[data.reshape(m, N // 2)]          # rows are whole bytes
-            if (N // 2) % 2:
-                nib = np.concatenate([nib, np.zeros((m, 1), np.uint8)], axis=1)
-            return (nib[:, 0::2] | (nib[:, 1::2] << 4)).astype(np.uint8)
-        v = np.empty((data.size, 4), dtype=np.uint8)
-        for k in range(4):
-            v[:, k] = (data >> (2 * k)) & 3
-        al = v.reshape(-1)[(bits0 % 8) // 2:][:m * N * 2].reshape(m, N, 2)
-        ds = ((al != 0) & (al != 3)).sum(axis=2).astype(np.uint8)
-        ds[(al == 3).any(axis=2)] = 3
-        if sample_sel is not None:
-            ds = ds[:, sample_sel]
-        return pack_dosage_2bit(ds)
+        sel = None if sample_sel is None else np.asarray(sample_sel, dtype=np.int64)
+        n_out = N if sel is None else int(sel.size)
+        nb = (n_out + 3) // 4
+        if out is None:
+            out = np.zeros((m, nb), dtype=np.uint8)
+        elif out.shape[0] < m or out.shape[1] < nb or out.dtype != np.uint8:
+            raise ValueError("dosage_alt_packed_range: `out` too small")
+        res = out[:m]
+        if res.shape[1] > nb:
+            res[:, nb:] = 0
+        # variants per piece: the allele bytes of a piece (N / 2 each) and, for a sample subset, one byte per
+        # selected (variant, sample) stay under chunk_bytes
+        per = N // 2 + 1 + (2 * n_out if sel is not None else 0) + nb
+        step = max(1, min(m, chunk_bytes // per)) if m else 1
+        lut = self._nibble_lut()
+        for a in range(0, m, step):
+            b = min(m, a + step)
+            k = b - a
+            bits0, bits1 = (v0 + a) * N * 4, (v0 + b) * N * 4
+            data = np.frombuffer(self.raw_range("genotype/data", bits0 // 8, (bits1 + 7) // 8), dtype=np.uint8)
+            if N % 2 == 0:
+                nib = lut[data.reshape(k, N // 2)]                  # per byte: the dosage codes of two samples
+                if sel is None:
+                    if (N // 2) % 2:
+                        nib = np.concatenate([nib, np.zeros((k, 1), np.uint8)], axis=1)
+                    np.bitwise_or(nib[:, 0::2], nib[:, 1::2] << 4, out=res[a:b, :nb])
+                    continue
+                codes = (nib[:, sel >> 1] >> ((sel & 1) << 1).astype(np.uint8)) & 3          # [k, n_out] uint8
+            else:
+                # an odd number of samples: rows are not whole bytes -- through the 2-bit allele codes
+                al = np.empty((data.size, 4), dtype=np.uint8)
+                for q in range(4):
+                    al[:, q] = (data >> (2 * q)) & 3
+                al = al.reshape(-1)[(bits0 % 8) // 2:][:k * N * 2].reshape(k, N, 2)
+                codes = ((al[:, :, 0] != 0) & (al[:, :, 0] != 3)).astype(np.uint8) + ((al[:, :, 1] != 0) & (al[:, :, 1] != 3))
+                codes[(al[:, :, 0] == 3) | (al[:, :, 1] == 3)] = 3
+                if sel is not None:
+                    codes = codes[:, sel]
+            res[a:b, :nb] = pack_dosage_2bit(codes)
+        return res if res.shape[1] == nb else res
 
     def dosage_alt_packed(self) -> Tuple[np.ndarray, int, int]:
         """``$dosage_alt`` of every variant (see ``dosage_alt_packed_range``) -> (packed, N, M)."""
@@ -470,6 +526,133 @@ def _decode_xz(s: bytes, ra: bool) -> bytes:
         pos = len(s) - len(d.unused_data)
         done += 1
     return b"".join(out)
+
+
+def _packed_real16(raw: np.ndarray, cls: str, scale: float, offset: float) -> np.ndarray:
+    """dPackedReal16U: value = raw * scale + offset, 0xFFFF = NaN; dPackedReal16: signed, -32768 = NaN."""
+    if cls == "dPackedReal16U":
+        out = raw.astype(np.float64) * scale + offset
+        out[raw == 0xFFFF] = np.nan
+    else:
+        sv = raw.view(np.int16)
+        out = sv.astype(np.float64) * scale + offset
+        out[sv == -32768] = np.nan
+    return out
+
+
+def lz4_block_decode(src: bytes, raw_size: Optional[int] = None) -> bytes:
+    """LZ4 block format (sequences of literals + matches), pure Python: the test-sized streams only."""
+    out = bytearray()
+    i, n = 0, len(src)
+    while i < n:
+        tok = src[i]
+        i += 1
+        ll = tok >> 4
+        if ll == 15:
+            while True:
+                c = src[i]
+                i += 1
+                ll += c
+                if c != 255:
+                    break
+        out += src[i:i + ll]
+        i += ll
+        if i >= n:
+            break
+        off = src[i] | (src[i + 1] << 8)
+        i += 2
+        if off == 0:
+            raise GdsError("LZ4: zero offset")
+        ml = (tok & 15) + 4
+        if (tok & 15) == 15:
+            while True:
+                c = src[i]
+                i += 1
+                ml += c
+                if c != 255:
+                    break
+        st = len(out) - off
+        if st < 0:
+            raise GdsError("LZ4: offset before the start of the block")
+        for k in range(ml):                 # overlapping copies are the format's run-length trick
+            out.append(out[st + k])
+    if raw_size is not None and len(out) != raw_size:
+        raise GdsError("LZ4: block size mismatch")
+    return bytes(out)
+
+
+def lz4_block_encode(raw: bytes) -> bytes:
+    """A valid (not a good) LZ4 block: greedy 4-byte hash matches; for the writer's test files."""
+    n, i, anchor = len(raw), 0, 0
+    out = bytearray()
+    table: Dict[bytes, int] = {}
+
+    def emit(lit: bytes, off: int, ml: int):
+        tok_l = min(len(lit), 15)
+        tok_m = min(ml - 4, 15) if ml else 0
+        out.append((tok_l << 4) | tok_m)
+        if len(lit) >= 15:
+            r = len(lit) - 15
+            while r >= 255:
+                out.append(255)
+                r -= 255
+            out.append(r)
+        out.extend(lit)
+        if ml:
+            out.extend((off & 0xFF, off >> 8))
+            if ml - 4 >= 15:
+                r = ml - 4 - 15
+                while r >= 255:
+                    out.append(255)
+                    r -= 255
+                out.append(r)
+
+    while i + 12 < n:                       # the last 12 bytes stay literals (format rule: 5, kept simple)
+        key = raw[i:i + 4]
+        j = table.get(key)
+        table[key] = i
+        if j is not None and i - j <= 0xFFFF:
+            ml = 4
+            while i + ml < n - 5 and raw[j + ml] == raw[i + ml]:
+                ml += 1
+            emit(raw[anchor:i], i - j, ml)
+            i += ml
+            anchor = i
+        else:
+            i += 1
+    emit(raw[anchor:], 0, 0)
+    return bytes(out)
+
+
+def _decode_block(kind: str, blk: bytes, raw_size: Optional[int]) -> bytes:
+    """One block of a random-access stream (or a whole single-stream payload)."""
+    if kind == "xz":
+        return lzma.LZMADecompressor(format=lzma.FORMAT_XZ).decompress(blk)
+    if kind == "zip":
+        for wbits in (15, -15, 31):          # zlib header, raw deflate, gzip
+            try:
+                return zlib.decompressobj(wbits).decompress(blk)
+            except zlib.error:
+                continue
+        raise GdsError("ZIP block: not a zlib / deflate / gzip stream")
+    if kind == "lz4":
+        if blk[:4] == b"\x04\x22\x4d\x18":   # LZ4 frame: descriptor, then blocks (u32 size, bit 31 = stored)
+            flg = blk[4]
+            p = 6 + (8 if flg & 0x08 else 0) + (4 if flg & 0x01 else 0) + 1
+            out = []
+            while True:
+                bs = struct.unpack_from("<I", blk, p)[0]
+                p += 4
+                if bs == 0:
+                    break
+                body = blk[p:p + (bs & 0x7FFFFFFF)]
+                p += bs & 0x7FFFFFFF
+                out.append(body if bs >> 31 else lz4_block_decode(body))
+                if flg & 0x10:
+                    p += 4
+            return b"".join(out)
+        return lz4_block_decode(blk, raw_size)
+    raise GdsError(f"unknown block coder {kind!r}")
 
 
 def pack_dosage_2bit(ds: np.ndarray) -> np.ndarray:

@@ -88,39 +88,73 @@ def _node_stream(nprop: int, body: bytes) -> bytes:
     return _u48(8 + len(body)) + struct.pack("<H", nprop) + body
 
 
-def _lzma_ra(raw: bytes) -> bytes:
+def _ra_stream(raw: bytes, kind: str = "xz", block: int = _RA_BLOCK):
+    """gdsfmt's random-access stream: 18-byte header, independent blocks, then the block index.  kind: "xz"
+    (LZMA_RA: the framing of the reference's own files), "zip" (zlib blocks), "lz4" (LZ4 blocks) -- the last
+    two in the same framing by analogy; no file of the reference pins them."""
+    import zlib
+    from .gds import lz4_block_encode
+    magic = {"xz": b"XZ_RA\x10\x11", "zip": b"ZIP_RA\x10", "lz4": b"LZ4_RA\x10"}[kind]
     blocks, index = [], b""
-    for off in range(0, max(len(raw), 1), _RA_BLOCK):
-        piece = raw[off:off + _RA_BLOCK]
-        xz = lzma.compress(piece, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC32, preset=6)
-        if len(xz) >= 1 << 24:
-            raise ValueError("LZMA_RA block does not fit its 24-bit size field")
-        blocks.append(xz)
-        index += len(xz).to_bytes(3, "little") + struct.pack("<I", len(piece))
+    for off in range(0, max(len(raw), 1), block):
+        piece = raw[off:off + block]
+        if kind == "xz":
+            z = lzma.compress(piece, format=lzma.FORMAT_XZ, check=lzma.CHECK_CRC32, preset=6)
+        elif kind == "zip":
+            z = zlib.compress(piece, 6)
+        else:
+            z = lz4_block_encode(piece)
+        if len(z) >= 1 << 24:
+            raise ValueError("random-access block does not fit its 24-bit size field")
+        blocks.append(z)
+        index += len(z).to_bytes(3, "little") + struct.pack("<I", len(piece))
     body = b"".join(blocks)
-    return b"XZ_RA\x10\x11\xff" + struct.pack("<I", len(blocks)) + _u48(len(body)) + body + index, len(blocks)
+    return magic + b"\xff" + struct.pack("<I", len(blocks)) + _u48(len(body)) + body + index, len(blocks)
+
+
+def _lzma_ra(raw: bytes):
+    return _ra_stream(raw, "xz")
+
+
+_P_OFFSET = b"\x13\x86\x16E\x1e\xf4\x01"
+_P_SCALE = b"\x13\x85\xe70\x17\x04"
 
 
 class GdsWriter:
-    """Flat GDS file: array nodes under the root, string attributes on the root."""
+    """GDS file: array nodes in folders ("genotype/data"), string attributes on the root."""
 
     def __init__(self, path: str):
         self.path = path
-        self._nodes: List[Tuple[str, bytes, bytes]] = []     # name, node stream (data id patched at close), data stream
+        # tree: name -> ("array", node stream with the data id to be patched, data stream) | ("folder", children)
+        self._tree: Dict[str, Any] = {}
         self._root_attrs: List[Tuple[str, Optional[str]]] = []
 
     def put_attr(self, name: str, value: str):
         self._root_attrs.append((name, value))
 
-    def add(self, name: str, values: Any, compress: str = "LZMA_RA"):
-        """add.gdsn(root, name, values, compress=, closezip=TRUE)"""
+    def _slot(self, name: str):
+        parts = [p for p in name.split("/") if p]
+        cur = self._tree
+        for p in parts[:-1]:
+            cur = cur.setdefault(p, ("folder", {}))[1]
+        return cur, parts[-1]
+
+    def add(self, name: str, values: Any, compress: str = "LZMA_RA", cls: Optional[str] = None,
+            dims: Optional[Sequence[int]] = None, scale: Optional[float] = None, offset: Optional[float] = None,
+            ra_block: int = _RA_BLOCK):
+        """add.gdsn(node, name, values, compress=, closezip=TRUE).  cls / dims: store ``values`` (raw bytes or a
+        uint8 array) as that class with those dimensions -- dBit2 allele codes, dPackedReal8U/16U dosages
+        (with scale / offset)."""
         attrs: List[Tuple[str, Optional[str]]] = []
-        if isinstance(values, (list, tuple)) and (len(values) == 0 or isinstance(values[0], str)):
-            cls, n = "dStr8", len(values)
+        if cls is not None:
+            raw = values if isinstance(values, (bytes, bytearray)) else np.ascontiguousarray(values).tobytes()
+            dims = tuple(int(d) for d in dims)
+        elif isinstance(values, (list, tuple)) and (len(values) == 0 or isinstance(values[0], str)):
+            cls, dims = "dStr8", (len(values),)
             raw = b"".join(_varint(len(b)) + b for b in (str(v).encode("utf-8") for v in values))
         else:
             a = np.asarray(values)
-            n = a.size
+            dims = (a.size,)
             if a.dtype == np.bool_:
                 cls, raw = "dInt32", a.astype("<i4").tobytes()
                 attrs.append(("R.logical", None))
@@ -132,47 +166,107 @@ class GdsWriter:
                 raise TypeError(f"{name}: cannot store {a.dtype}")
         body = b"\x00\x01" + _pack7(cls)
         nprop = 0
-        if compress and compress.lower() != "none":
-            # every compressed flavour is written as LZMA_ra (the coder whose stream layout is known from
-            # the reference's files); only the file size depends on res.compress
-            data, nblk = _lzma_ra(raw)
-            body += _R_PIPE + b"\x07LZMA_ra" + _R_PIPE_SIZE + struct.pack("<qq", len(raw), len(data) - 7 * nblk)
+        comp = (compress or "none").upper()
+        if comp != "NONE":
+            # LZMA and LZMA_RA are written as LZMA_ra (the coder whose stream layout is known from the
+            # reference's files); ZIP_RA / LZ4_RA in the same framing with their own block coder
+            kind = "zip" if comp.startswith("ZIP") else "lz4" if comp.startswith("LZ4") else "xz"
+            data, nblk = _ra_stream(raw, kind, ra_block)
+            pname = {"xz": b"LZMA_ra", "zip": b"ZIP_ra", "lz4": b"LZ4_ra"}[kind]
+            body += _R_PIPE + bytes([len(pname)]) + pname + _R_PIPE_SIZE + struct.pack("<qq", len(raw), len(data) - 7 * nblk)
             body += _R_PIPE_LEVEL + _R_PIPE_BLOCK
             nprop += 4
         else:
             data = raw
-        body += _R_DCNT + struct.pack("<H", 1) + _R_DIM + b"\x04" + struct.pack("<i", n)
+        body += _R_DCNT + struct.pack("<H", len(dims)) + _R_DIM + bytes([4 * len(dims)]) + struct.pack("<%di" % len(dims), *dims)
         body += _R_DATA + b"\xff\xff\xff\xff"               # data stream id, patched in close()
+        nprop += 3
+        if offset is not None:
+            body += _P_OFFSET + struct.pack("<d", float(offset))
+            nprop += 1
+        if scale is not None:
+            body += _P_SCALE + struct.pack("<d", float(scale))
+            nprop += 1
         body += _attrs(attrs)
-        nprop += 4 + (1 if attrs else 0)
-        self._nodes.append((name, _node_stream(nprop, body), data))
+        nprop += 1 + (1 if attrs else 0)
+        cur, leaf = self._slot(name)
+        cur[leaf] = ("array", _node_stream(nprop, body), data)
 
     def close(self):
         streams: Dict[int, bytes] = {}
-        entries = b""
-        next_id = 2
-        for name, node, data in self._nodes:
-            nid, did = next_id, next_id + 1
-            next_id += 2
-            k = node.index(_R_DATA + b"\xff\xff\xff\xff")
-            streams[nid] = node[:k + len(_R_DATA)] + struct.pack("<I", did) + node[k + len(_R_DATA) + 4:]
-            streams[did] = data
-            nb = name.encode()
-            rec = _R_ENTRY_ID + struct.pack("<I", nid) + _R_ENTRY_FLAG + struct.pack("<I", 0) + _R_ENTRY_NAME + bytes([len(nb)]) + nb
-            entries += _u48(8 + len(rec)) + struct.pack("<H", 3) + rec
-        body = _R_DIRCNT + struct.pack("<I", len(self._nodes))
-        nprop = 1
-        if self._nodes:
-            body += _R_DIRLIST + _u48(6 + len(entries)) + entries
-            nprop += 1
-        body += _attrs(self._root_attrs)
-        nprop += 1 + (1 if self._root_attrs else 0)
-        streams[1] = _node_stream(nprop, body)
+        counter = [2]
+
+        def folder_stream(children: Dict[str, Any], root_attrs) -> bytes:
+            entries = b""
+            for name, node in children.items():
+                nid = counter[0]
+                counter[0] += 1
+                if node[0] == "array":
+                    did = counter[0]
+                    counter[0] += 1
+                    ns = node[1]
+                    k = ns.index(_R_DATA + b"\xff\xff\xff\xff")
+                    streams[nid] = ns[:k + len(_R_DATA)] + struct.pack("<I", did) + ns[k + len(_R_DATA) + 4:]
+                    streams[did] = node[2]
+                    flag = 0
+                else:
+                    streams[nid] = folder_stream(node[1], None)
+                    flag = 2
+                nb = name.encode()
+                rec = (_R_ENTRY_ID + struct.pack("<I", nid) + _R_ENTRY_FLAG + struct.pack("<I", flag) + _R_ENTRY_NAME
+                       + bytes([len(nb)]) + nb)
+                entries += _u48(8 + len(rec)) + struct.pack("<H", 3) + rec
+            body = _R_DIRCNT + struct.pack("<I", len(children))
+            nprop = 1
+            if children:
+                body += _R_DIRLIST + _u48(6 + len(entries)) + entries
+                nprop += 1
+            body += _attrs(root_attrs or [])
+            nprop += 1 + (1 if root_attrs else 0)
+            return _node_stream(nprop, body)
+
+        streams[1] = folder_stream(self._tree, self._root_attrs)
         with open(self.path, "wb") as f:
             f.write(_MAGIC + b"\x00\x01" + struct.pack("<I", 1))
             for sid in sorted(streams):
                 s = streams[sid]
                 f.write(_u48((22 + len(s)) | (1 << 47)) + _u48(0) + struct.pack("<I", sid) + _u48(len(s)) + s)
+
+
+def write_seqarray_genotypes(fn: str, packed: np.ndarray, n_samp: int, sample_id: Optional[Sequence[str]] = None,
+                             compress: str = "none", chromosome: str = "1", ra_block: int = _RA_BLOCK):
+    """A SeqArray-style genotype file from 2-bit dosage rows (``packed``: [M, >= ceil(N / 4)], code = alt-allele
+    count, 3 = missing): sample.id, variant.id, position, chromosome, allele, genotype/data (dBit2
+    [variant, sample, ploidy]) and genotype/@data -- what seqAssocGLMM_SPA reads (R/assoc_single.r:116-144).
+    The test and benchmark generator; dosage d is stored as alleles (1, 0) / (1, 1), missing as (3, 3)."""
+    packed = np.ascontiguousarray(packed, dtype=np.uint8)
+    M = packed.shape[0]
+    nb = (n_samp + 3) // 4
+    # one packed byte (4 dosage codes) -> 16 bits (4 samples x 2 alleles x 2 bits)
+    nib = np.array([0b0000, 0b0001, 0b0101, 0b1111], dtype=np.uint16)
+    lut = np.zeros(256, dtype=np.uint16)
+    for b in range(256):
+        lut[b] = sum(int(nib[(b >> (2 * k)) & 3]) << (4 * k) for k in range(4))
+    al = lut[packed[:, :nb]].astype("<u2")                      # [M, nb] -> 2 bytes per 4 samples
+    rows = al.view(np.uint8).reshape(M, 2 * nb)
+    row_bits = n_samp * 4
+    if row_bits % 8 == 0:
+        raw = np.ascontiguousarray(rows[:, :row_bits // 8]).tobytes()
+    else:
+        # rows are not whole bytes: through a bit stream
+        bits = np.unpackbits(rows, axis=1, bitorder="little")[:, :row_bits].reshape(-1)
+        raw = np.packbits(bits, bitorder="little").tobytes()
+    w = GdsWriter(fn)
+    w.put_attr("FileFormat", "SEQ_ARRAY")
+    sid = [f"s{i + 1}" for i in range(n_samp)] if sample_id is None else [str(x) for x in sample_id]
+    w.add("sample.id", sid, "none")
+    w.add("variant.id", np.arange(1, M + 1), "none")
+    w.add("position", np.arange(1, M + 1) * 100, "none")
+    w.add("chromosome", [chromosome] * M, "none")
+    w.add("allele", ["A,C"] * M, "none")
+    w.add("genotype/data", raw, compress, cls="dBit2", dims=(M, n_samp, 2), ra_block=ra_block)
+    w.add("genotype/@data", np.ones(M, dtype=np.uint8).tobytes(), "none", cls="dUInt8", dims=(M,))
+    w.close()
 
 
 def write_saige_output(fn: str, ans: Dict[str, Any], sample_id: Sequence[str], compress: str = "LZMA",

@@ -18,7 +18,7 @@ from typing import Any, Optional, Sequence
 
 import numpy as np
 
-from .rds import RList, read_rds
+from .rds import read_rdata, RList, read_rds
 
 
 class ModelError(ValueError):
@@ -78,8 +78,14 @@ def load_modobj(modobj: Any, verbose: bool = False) -> NullModel:
         if low.endswith(".rds"):
             return modobj_from_rlist(read_rds(modobj))
         if low.endswith(".rda") or low.endswith(".rdata"):
-            raise ModelError("RData model files are not supported by this build; "
-                             "save the model with saveRDS() (model.savefn='*.rds').")
+            # modobj <- get(load(modobj)), R/saige_main.r:98-100: the first object of the file
+            objs = read_rdata(modobj)
+            if not objs:
+                raise ModelError(f"'{modobj}' holds no object.")
+            first = next(iter(objs.values()))
+            if not isinstance(first, RList):
+                raise ModelError(f"the object in '{modobj}' is not a list.")
+            return modobj_from_rlist(first)
         raise ModelError("It should be an RData, RDS or gds file.")
     raise ModelError("'modobj' should be a NullModel, a parsed RDS list or a file name.")
 

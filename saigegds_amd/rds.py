@@ -377,6 +377,21 @@ def read_rds(path: str) -> Any:
     return loads(_decompress(raw))
 
 
+def read_rdata(path: str) -> Dict[str, Any]:
+    """Parse an ``.rda`` / ``.RData`` file written by ``save()``: the magic line "RDX2" / "RDX3", then one
+    serialised pairlist whose tags are the object names -> {name: object} in file order."""
+    with open(path, "rb") as f:
+        raw = _decompress(f.read())
+    if raw[:5] not in (b"RDX2\n", b"RDX3\n"):
+        raise RdsError("not an RData file (header %r): only the XDR form written by save() is supported" % raw[:5])
+    pl = loads(raw[5:])
+    if isinstance(pl, RList):
+        return {str(k): v for k, v in zip(pl.names or [], pl.values)}
+    if isinstance(pl, dict):
+        return {str(k): v for k, v in pl.items()}
+    raise RdsError("RData: the top-level object is not a pairlist")
+
+
 def loads(buf: bytes) -> Any:
     if buf[:2] != b"X\n":
         raise RdsError("only XDR-format RDS is supported (header %r)" % buf[:2])

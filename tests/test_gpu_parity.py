@@ -252,6 +252,65 @@ def test_seqAssocGLMM_SPA_driver(grm1k, golden_bin, tmp_path):
     assert np.max(np.abs(np.asarray(r["pval"]) / golden_bin["pval"][keep] - 1)) <= 1e-10
 
 
+def test_file_to_table_equals_in_memory_scan(grm1k, tmp_path, monkeypatch):
+    """seqAssocGLMM_SPA on GDS files written by the committed generator (genotype/data raw, LZMA_RA, ZIP_RA,
+    LZ4_RA) = the scan of the same rows from memory, bit for bit: the whole ingest path (block-wise decode
+    one block ahead, pinned pipeline, block load on the device) moves nothing.  With the model's samples a
+    reordered subset of the file's (selection in the 2-bit domain) the counts stay exact and the statistics
+    move by rounding only (the sums run in the file's sample order).  An .rda model file gives the same table."""
+    from types import SimpleNamespace
+    from conftest import load_null_model
+    from saigegds_amd import GenotypeSource, seqAssocGLMM_SPA
+    from saigegds_amd import assoc as assoc_mod
+    from saigegds_amd.gds_write import write_seqarray_genotypes
+    from saigegds_amd.results import save_model
+    mod = load_null_model("saige_model.npz")
+    n = 1000
+    m = 2300
+    pk = grm1k["packed"][:m]
+    # the file holds 1 000 + 7 samples in another order than the model
+    rng = np.random.default_rng(3)
+    from saigegds_amd.gds import pack_dosage_2bit, unpack_dosage_2bit
+    codes = unpack_dosage_2bit(pk, n)
+    perm = rng.permutation(n + 7)
+    wide = np.concatenate([codes, rng.integers(0, 3, (m, 7)).astype(np.uint8)], axis=1)[:, perm]
+    sid_all = ([str(s) for s in grm1k["sample_id"]] + [f"extra{i}" for i in range(7)])
+    sid_file = [sid_all[i] for i in perm]
+    monkeypatch.setattr(assoc_mod, "BLOCK_SIZE", 600)            # four blocks: decode runs ahead of the scan
+    src = GenotypeSource([str(s) for s in grm1k["sample_id"]], packed=pk)
+    ref = seqAssocGLMM_SPA(src, mod, mac=4, verbose=False)
+    assert len(ref["pval"]) > 1500
+    for comp in ("none", "LZMA_RA", "ZIP_RA", "LZ4_RA"):
+        fn = str(tmp_path / f"same_{comp}.gds")
+        write_seqarray_genotypes(fn, pk, n, sample_id=[str(s) for s in grm1k["sample_id"]], compress=comp, ra_block=100_000)
+        tm = {}
+        ans = seqAssocGLMM_SPA(fn, mod, mac=4, verbose=False, timing=tm)
+        assert tm["decode_s"] > 0 and tm["scan_s"] > 0
+        for c in ("AF.alt", "mac", "num", "beta", "SE", "pval", "p.norm", "converged"):
+            assert np.array_equal(np.asarray(ans[c]), np.asarray(ref[c])), (comp, c)
+        # a reordered superset of the model's samples
+        fn = str(tmp_path / f"geno_{comp}.gds")
+        write_seqarray_genotypes(fn, pack_dosage_2bit(wide), n + 7, sample_id=sid_file, compress=comp, ra_block=100_000)
+        ans = seqAssocGLMM_SPA(fn, mod, mac=4, verbose=False)
+        for c in ("AF.alt", "mac", "num", "converged"):
+            assert np.array_equal(np.asarray(ans[c]), np.asarray(ref[c])), (comp, c)
+        for c in ("beta", "SE", "pval", "p.norm"):
+            np.testing.assert_allclose(np.asarray(ans[c]), np.asarray(ref[c]), rtol=1e-10, err_msg=f"{comp} {c}")
+    # the model from an .rda file
+    nr = len(mod.var_ratio)
+    full = SimpleNamespace(
+        coefficients=np.zeros(3), coef_names=None, tau=mod.tau, linear_predictors=np.zeros(n), fitted_values=mod.fitted_values,
+        residuals=mod.y - mod.fitted_values, cov=np.eye(3), converged=True, y=mod.y, mu_noK=mod.fitted_values,
+        res_noK=mod.y - mod.fitted_values, V=mod.V, X1=mod.X1, XV=mod.XV, XXVX_inv=mod.XXVX_inv, trait_type=mod.trait_type,
+        sample_id=list(mod.sample_id), variant_id=np.arange(1, 4),
+        var_ratio_table={"id": np.arange(1, nr + 1), "maf": np.full(nr, 0.1), "mac": np.full(nr, 30.0), "var1": np.ones(nr),
+                         "var2": np.ones(nr), "ratio": np.asarray(mod.var_ratio)})
+    mfn = str(tmp_path / "model.rda")
+    save_model(full, mfn)
+    ans = seqAssocGLMM_SPA(str(tmp_path / "same_ZIP_RA.gds"), mfn, mac=4, verbose=False)
+    assert np.array_equal(np.asarray(ans["pval"]), np.asarray(ref["pval"]))
+
+
 @pytest.mark.parametrize("option,value,counter", [
     ("spa_exact", 1, "n_spa_slow"),       # every flagged variant through the exact exp/log kernel
     ("force_dense", 1, "n_spa_dense"),    # exact g_pos / g_neg pass (SPATest.cpp:328-332)

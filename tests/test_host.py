@@ -253,3 +253,126 @@ def test_scan_blocks_runs_one_thread_per_gpu():
         return np.zeros((hi - lo, 1), np.uint8)
     with pytest.raises(RuntimeError, match="decode failed"):
         scan_blocks(FakeScanner, 2, blocks, bad_read, True, out, valid)
+
+
+def test_scan_blocks_decodes_one_block_ahead():
+    """Each scanner's decoder thread works on block i + 1 while block i is being scanned: with a decode and a
+    scan of equal length the wall time is ~ (n + 1) x one of them, not 2 n; the timing dict adds them up."""
+    import time
+    from saigegds_amd.assoc import scan_blocks
+    events = []
+
+    class FakeScanner:
+        def __init__(self, d):
+            pass
+
+        def scan_2bit(self, blk):
+            events.append(("scan+", int(blk[0, 0])))
+            time.sleep(0.06)
+            events.append(("scan-", int(blk[0, 0])))
+            return np.zeros((blk.shape[0], 8)), np.ones(blk.shape[0], np.uint8)
+
+        def close(self):
+            pass
+
+    def read(lo, hi):
+        events.append(("dec+", lo // 10))
+        time.sleep(0.06)
+        events.append(("dec-", lo // 10))
+        return np.full((hi - lo, 1), lo // 10, np.uint8)
+    n = 6
+    blocks = [(10 * i, 10 * i + 10) for i in range(n)]
+    out, valid, timing = np.zeros((10 * n, 8)), np.zeros(10 * n, np.uint8), {}
+    t = time.perf_counter()
+    scan_blocks(FakeScanner, 1, blocks, read, True, out, valid, timing)
+    wall = time.perf_counter() - t
+    assert wall < 0.06 * (2 * n) * 0.8, wall                    # overlapped: far from the serial 2 n x 60 ms
+    assert valid.all() and timing["decode_s"] >= 0.06 * n * 0.9 and timing["scan_s"] >= 0.06 * n * 0.9
+    # block i + 1 starts decoding before block i has been scanned
+    for i in range(n - 1):
+        assert events.index(("dec+", i + 1)) < events.index(("scan-", i)), (i, events)
+
+
+def test_gds_codecs_and_bounded_block_decode(tmp_path):
+    """genotype/data through every storage the reader knows (raw, LZMA_RA, ZIP_RA, LZ4_RA), an odd sample
+    count, a sample subset taken in the 2-bit domain, a caller's buffer, tiny work pieces -- all equal to
+    the in-memory codes; 8- and 16-bit packed reals."""
+    import tracemalloc
+    from saigegds_amd import synth
+    from saigegds_amd.gds import GdsFile, pack_dosage_2bit, unpack_dosage_2bit
+    from saigegds_amd.gds_write import GdsWriter, write_seqarray_genotypes
+    for n in (1003, 1000):
+        m = 150
+        pk = synth.synth_packed(n, 0, m, 5, synth.variant_thresholds(0, m, 5))[:, :(n + 3) // 4]
+        codes = unpack_dosage_2bit(pk, n)
+        sel = np.arange(n)[::-3].copy()
+        for comp in ("none", "LZMA_RA", "ZIP_RA", "LZ4_RA"):
+            fn = str(tmp_path / f"g_{n}_{comp}.gds")
+            write_seqarray_genotypes(fn, pk, n, compress=comp, ra_block=30_000)
+            f = GdsFile(fn)
+            assert f.genotype_dims() == (m, n) and len(f.sample_id()) == n
+            got, N, M = f.dosage_alt_packed()
+            assert (N, M) == (n, m) and np.array_equal(got, pk)
+            sub = f.dosage_alt_packed_range(10, 131, sel, chunk_bytes=4000)
+            assert np.array_equal(sub, pack_dosage_2bit(codes[10:131][:, sel]))
+            buf = np.full((200, (n + 3) // 4 + 5), 0xAB, np.uint8)
+            res = f.dosage_alt_packed_range(0, m, out=buf)
+            assert np.array_equal(res[:, :(n + 3) // 4], pk) and not res[:, (n + 3) // 4:].any()
+    # the work pieces bound the temporaries: a block of 4 000 x 20 000 with a sample subset stays far under
+    # the 80 MB of one byte per (variant, sample)
+    n, m = 20_000, 4_000
+    pk = np.zeros((m, n // 4), np.uint8)
+    pk[:, ::7] = 0x61
+    fn = str(tmp_path / "big.gds")
+    write_seqarray_genotypes(fn, pk, n)
+    f = GdsFile(fn)
+    sel = np.arange(0, n, 2)
+    tracemalloc.start()
+    sub = f.dosage_alt_packed_range(0, m, sel, chunk_bytes=4 << 20)
+    peak = tracemalloc.get_traced_memory()[1]
+    tracemalloc.stop()
+    assert np.array_equal(sub[:50], pack_dosage_2bit(unpack_dosage_2bit(pk[:50], n)[:, sel]))
+    assert peak < 40 << 20, peak
+    # packed reals
+    w = GdsWriter(str(tmp_path / "ds.gds"))
+    raw16 = np.array([[0, 1000, 20000, 0xFFFF], [5, 6, 7, 8]], dtype="<u2")
+    raw8 = np.array([[0, 127, 254, 0xFF]], dtype=np.uint8)
+    w.add("annotation/format/DS/data", raw16, "ZIP_RA", cls="dPackedReal16U", dims=raw16.shape, scale=1e-4, offset=0.0)
+    w.add("annotation/format/D8/data", raw8, "none", cls="dPackedReal8U", dims=raw8.shape, scale=1 / 127, offset=0.0)
+    w.add("sample.id", ["a", "b", "c", "d"], "none")
+    w.close()
+    g = GdsFile(str(tmp_path / "ds.gds"))
+    d16 = g.dosage_real_range("annotation/format/DS", 0, 2)
+    assert np.allclose(d16[0, :3], [0, 0.1, 2.0]) and np.isnan(d16[0, 3]) and np.allclose(d16[1], np.array([5, 6, 7, 8]) * 1e-4)
+    assert np.array_equal(g.read("annotation/format/DS/data"), d16, equal_nan=True)
+    d8 = g.read("annotation/format/D8/data")
+    assert np.allclose(d8[0, :3], [0, 1, 2]) and np.isnan(d8[0, 3])
+
+
+def test_model_files_rds_and_rda(tmp_path):
+    """.check_modobj loads .rda / .RData as well as .rds (R/saige_main.r:93-111): a model saved in both forms
+    comes back identical, field by field, and equal to what was saved."""
+    from types import SimpleNamespace
+    from saigegds_amd.nullmod import load_modobj
+    from saigegds_amd.results import save_model
+    mod = load_null_model("saige_model.npz")
+    n = len(mod.sample_id)
+    nr = len(mod.var_ratio)
+    full = SimpleNamespace(
+        coefficients=np.array([0.1, -0.2, 0.3]), coef_names=["(Intercept)", "x1", "x2"], tau=mod.tau,
+        linear_predictors=np.linspace(-2, 2, n), fitted_values=mod.fitted_values, residuals=mod.y - mod.fitted_values,
+        cov=np.eye(3), converged=True, y=mod.y, mu_noK=mod.fitted_values * 0.99, res_noK=mod.y - mod.fitted_values * 0.99,
+        V=mod.V, X1=mod.X1, XV=mod.XV, XXVX_inv=mod.XXVX_inv, trait_type=mod.trait_type, sample_id=list(mod.sample_id),
+        variant_id=np.arange(1, 6), var_ratio_table={"id": np.arange(1, nr + 1), "maf": np.full(nr, 0.1), "mac": np.full(nr, 30.0),
+                                                     "var1": np.ones(nr), "var2": np.ones(nr), "ratio": np.asarray(mod.var_ratio)})
+    a, b, c = str(tmp_path / "m.rds"), str(tmp_path / "m.rda"), str(tmp_path / "m.RData")
+    for fn in (a, b, c):
+        save_model(full, fn)
+    ma, mb, mc = load_modobj(a), load_modobj(b), load_modobj(c)
+    for got in (ma, mb, mc):
+        assert got.trait_type == mod.trait_type and [str(x) for x in got.sample_id] == [str(x) for x in mod.sample_id]
+        for fld in ("tau", "fitted_values", "var_ratio", "y", "V", "X1", "XV", "XXVX_inv"):
+            assert np.array_equal(np.asarray(getattr(got, fld)), np.asarray(getattr(mod, fld))), fld
+        assert np.array_equal(got.coefficients, full.coefficients)
+    with pytest.raises(Exception):
+        load_modobj(str(tmp_path / "m.txt"))
