@@ -195,6 +195,16 @@ int sgx_burden_2bit(sgx_handle *h, const uint8_t *packed, size_t bytes_per_varia
 	size_t n_variants, size_t n_rows, const int64_t *row_ptr, const int32_t *var_idx,
 	const double *lut, double *out8, uint8_t *valid);
 
+/* Host-side decoder of SeqArray's genotype/data node (dBit2 [variant][sample][ploidy]) into the 2-bit dosage
+ * rows of sgx_scan_2bit / sgx_block_load: code = number of non-reference alleles, 3 = missing -- SeqArray's
+ * "$dosage_alt", what seqApply(.useraw=NA) hands saige_score_test_bin as RAW (R/assoc_single.r:202-221).
+ * alleles: the node's bytes from the one that holds bit `bit0` (a multiple of 4) of the first wanted
+ * variant; sel: sample indices to keep, in the order wanted (NULL = all n_samp); out: m rows of out_stride
+ * bytes (a pinned block buffer, say).  threads: host threads to split the rows over (0 = automatic).
+ * Needs no GPU. */
+int sgx_decode_dbit2(const uint8_t *alleles, size_t bit0, int32_t n_samp, size_t m,
+	const int64_t *sel, int32_t n_sel, uint8_t *out, size_t out_stride, int threads);
+
 /* Per-variant counts of a HOST 2-bit matrix on GPU `device`: n_valid[j] = samples with a call,
  * allele_sum[j] = their alt-allele count -- the inputs of the maf / missing-rate variant filter of
  * seqFitNullGLMM_SPA (seqSetFilterCond, R/saige_main.r:314-321).  Needs no model handle. */

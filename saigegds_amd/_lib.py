@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libsaigehip.so")
 
 EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
-    "sgx_set_thresholds", "sgx_score_layout", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_i32", "sgx_scan_f64", "sgx_host_alloc", "sgx_host_free", "sgx_burden_2bit", "sgx_geno_stats_2bit",
+    "sgx_set_thresholds", "sgx_score_layout", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_i32", "sgx_scan_f64", "sgx_host_alloc", "sgx_host_free", "sgx_burden_2bit", "sgx_geno_stats_2bit", "sgx_decode_dbit2",
     "sgx_block_bytes", "sgx_block_create", "sgx_block_free", "sgx_block_load_dev", "sgx_block_load", "sgx_block_variants", "sgx_scan_block",
     "sgx_sync", "sgx_get_stats", "sgx_get_stats_total", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
     "sgx_grm_init", "sgx_grm_init_dev", "sgx_grm_crossprod_dev", "sgx_grm_sync", "sgx_grm_free", "sgx_grm_diag", "sgx_grm_crossprod", "sgx_grm_pcg",
@@ -128,6 +128,8 @@ def load():
     L.sgx_scan_i32.argtypes = [vp, vp, sz, vp, vp]
     L.sgx_burden_2bit.restype = C.c_int
     L.sgx_burden_2bit.argtypes = [vp, vp, sz, sz, sz, vp, vp, vp, vp, vp]
+    L.sgx_decode_dbit2.restype = C.c_int
+    L.sgx_decode_dbit2.argtypes = [vp, sz, C.c_int32, sz, vp, C.c_int32, vp, sz, C.c_int]
     L.sgx_geno_stats_2bit.restype = C.c_int
     L.sgx_geno_stats_2bit.argtypes = [vp, sz, C.c_int32, sz, C.c_int, vp, vp]
     L.sgx_set_option.restype = C.c_int
@@ -385,6 +387,24 @@ class PinnedBuffer:
 
     def __exit__(self, *exc):
         self.close()
+
+
+def decode_dbit2(alleles, bit0: int, n_samp: int, m: int, out: np.ndarray, sel: np.ndarray = None, threads: int = 0):
+    """SeqArray allele codes (bytes of genotype/data from bit ``bit0`` on) -> 2-bit dosage rows in ``out``
+    ([>= m, >= ceil(n / 4)] uint8, C-contiguous rows); ``sgx_decode_dbit2``, host threads, no GPU needed."""
+    L = load()
+    a = np.frombuffer(alleles, dtype=np.uint8) if not isinstance(alleles, np.ndarray) else alleles
+    if out.dtype != np.uint8 or out.ndim != 2 or out.strides[1] != 1 or out.shape[0] < m:
+        raise ValueError("decode_dbit2: out must be a [>= m, stride] uint8 array with contiguous rows")
+    need = (bit0 + m * n_samp * 4 + 7) // 8
+    if a.size < need:
+        raise ValueError("decode_dbit2: allele buffer too short")
+    sp, ns = None, 0
+    if sel is not None:
+        sel = np.ascontiguousarray(sel, dtype=np.int64)
+        sp, ns = sel.ctypes.data, int(sel.size)
+    check(L.sgx_decode_dbit2(a.ctypes.data, int(bit0), int(n_samp), int(m), sp, ns, out.ctypes.data, int(out.strides[0]), int(threads)))
+    return out
 
 
 def geno_stats_2bit(packed: np.ndarray, n_samp: int, device: int = 0):

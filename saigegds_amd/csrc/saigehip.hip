@@ -25,7 +25,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "saigehip.h"
@@ -1491,6 +1493,78 @@ extern "C" int sgx_burden_2bit(sgx_handle *h, const uint8_t *packed, size_t bpv,
 		total.score_launches += h->stats.score_launches; total.spa_launches += h->stats.spa_launches;
 	}
 	h->stats = total;
+	return SGX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Host-side decoder of SeqArray's genotype/data (dBit2 [variant][sample][ploidy], 2 bits per allele, LSB
+// first) into 2-bit dosage rows: code = number of non-reference alleles, 3 = missing (any allele missing) --
+// what seqGetData(gds, "$dosage_alt") yields and seqApply hands the reference as RAW (R/assoc_single.r:202-221).
+// alleles: the bytes that hold variants [0, m) starting at bit `bit0` of the first byte (rows are 4 n_samp
+// bits and need not be whole bytes).  sel: n_sel sample indices to keep, in the order wanted (NULL: all).
+// out: m rows of out_stride bytes; bytes beyond a row's codes are zeroed.  Rows are split over `threads`
+// host threads (0 = one per hardware thread, at most 16).
+extern "C" int sgx_decode_dbit2(const uint8_t *alleles, size_t bit0, int32_t n_samp, size_t m,
+	const int64_t *sel, int32_t n_sel, uint8_t *out, size_t out_stride, int threads)
+{
+	if (!alleles || !out) return fail(SGX_EINVAL, "sgx_decode_dbit2: NULL buffer");
+	if (n_samp <= 0 || (sel && n_sel <= 0)) return fail(SGX_EINVAL, "sgx_decode_dbit2: no samples");
+	const size_t n_out = sel ? (size_t)n_sel : (size_t)n_samp, nb = (n_out + 3) / 4;
+	if (out_stride < nb) return fail(SGX_EINVAL, "sgx_decode_dbit2: out_stride %zu < %zu", out_stride, nb);
+	if (sel) for (int32_t k = 0; k < n_sel; k++)
+		if (sel[k] < 0 || sel[k] >= n_samp) return fail(SGX_EINVAL, "sgx_decode_dbit2: sample index %lld out of range", (long long)sel[k]);
+	// nibble (two allele codes of one sample) -> dosage code
+	uint8_t nib[16];
+	for (int v = 0; v < 16; v++) {
+		const int a0 = v & 3, a1 = v >> 2;
+		nib[v] = (a0 == 3 || a1 == 3) ? 3 : (uint8_t)((a0 != 0) + (a1 != 0));
+	}
+	// two bytes (four samples) -> one packed byte
+	static std::vector<uint8_t> lut16;
+	static std::once_flag once;
+	std::call_once(once, [&]() {
+		lut16.resize(65536);
+		for (int w = 0; w < 65536; w++)
+			lut16[w] = (uint8_t)(nib[w & 15] | (nib[(w >> 4) & 15] << 2) | (nib[(w >> 8) & 15] << 4) | (nib[w >> 12] << 6));
+	});
+	const size_t row_bits = (size_t)n_samp * 4;
+	int T = threads > 0 ? threads : (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+	T = (int)std::min<size_t>((size_t)T, std::max<size_t>(1, m));
+	auto work = [&](size_t r0, size_t r1) {
+		for (size_t r = r0; r < r1; r++) {
+			const size_t b0 = bit0 + r * row_bits;
+			uint8_t *o = out + r * out_stride;
+			if (!sel && (b0 & 7) == 0) {
+				const uint8_t *p = alleles + (b0 >> 3);
+				const size_t full = (size_t)n_samp / 4;
+				for (size_t k = 0; k < full; k++) o[k] = lut16[(size_t)p[2 * k] | ((size_t)p[2 * k + 1] << 8)];
+				if (full < nb) {                                  // the last 1..3 samples
+					uint8_t v = 0;
+					for (size_t s = 4 * full; s < (size_t)n_samp; s++) {
+						const size_t bit = b0 + 4 * s;
+						v |= (uint8_t)(nib[(alleles[bit >> 3] >> (bit & 7)) & 15] << (2 * (s & 3)));
+					}
+					o[full] = v;
+				}
+			} else {
+				for (size_t k = 0; k < nb; k++) {
+					uint8_t v = 0;
+					for (size_t q = 0; q < 4 && 4 * k + q < n_out; q++) {
+						const size_t s = sel ? (size_t)sel[4 * k + q] : 4 * k + q;
+						const size_t bit = b0 + 4 * s;               // a nibble never straddles a byte: bit0 and 4 s are multiples of 4
+						v |= (uint8_t)(nib[(alleles[bit >> 3] >> (bit & 7)) & 15] << (2 * q));
+					}
+					o[k] = v;
+				}
+			}
+			if (out_stride > nb) memset(o + nb, 0, out_stride - nb);
+		}
+	};
+	if ((bit0 & 3) != 0) return fail(SGX_EINVAL, "sgx_decode_dbit2: bit0 must be a multiple of 4");
+	if (T <= 1) { work(0, m); return SGX_OK; }
+	std::vector<std::thread> th;
+	for (int t = 0; t < T; t++) th.emplace_back(work, m * t / T, m * (t + 1) / T);
+	for (auto &x : th) x.join();
 	return SGX_OK;
 }
 

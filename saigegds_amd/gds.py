@@ -427,11 +427,16 @@ class GdsFile:
         per = N // 2 + 1 + (2 * n_out if sel is not None else 0) + nb
         step = max(1, min(m, chunk_bytes // per)) if m else 1
         lut = self._nibble_lut()
+        native = _native_decoder() if res.strides[1] == 1 else None
         for a in range(0, m, step):
             b = min(m, a + step)
             k = b - a
             bits0, bits1 = (v0 + a) * N * 4, (v0 + b) * N * 4
             data = np.frombuffer(self.raw_range("genotype/data", bits0 // 8, (bits1 + 7) // 8), dtype=np.uint8)
+            if native is not None:
+                # libsaigehip's host decoder (sgx_decode_dbit2): rows over host threads, straight into `out`
+                native(data, bits0 % 8, N, k, res[a:b], sel)
+                continue
             if N % 2 == 0:
                 nib = lut[data.reshape(k, N // 2)]                  # per byte: the dosage codes of two samples
                 if sel is None:
@@ -526,6 +531,23 @@ def _decode_xz(s: bytes, ra: bool) -> bytes:
         pos = len(s) - len(d.unused_data)
         done += 1
     return b"".join(out)
+
+
+_NATIVE = [False, None]
+
+
+def _native_decoder():
+    """sgx_decode_dbit2 of libsaigehip.so when the library has been built (it needs no GPU); else None and
+    the numpy path below does the same thing."""
+    if not _NATIVE[0]:
+        _NATIVE[0] = True
+        try:
+            from . import _lib
+            _lib.load()
+            _NATIVE[1] = _lib.decode_dbit2
+        except Exception:       # noqa: BLE001 -- library not built: numpy path
+            _NATIVE[1] = None
+    return _NATIVE[1]
 
 
 def _packed_real16(raw: np.ndarray, cls: str, scale: float, offset: float) -> np.ndarray:
