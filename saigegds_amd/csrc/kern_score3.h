@@ -381,62 +381,109 @@ s3_ingest_tile_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int M
 	}
 }
 
-// ---- ingest 2 (one workgroup of 1024): per variant n3 and the overflow mark, then the exclusive prefix of the
-// listed counts in (range, variant) order.  A variant whose missing genotypes exceed `lim`, or that no longer
-// fits the block's list, is marked (ovf = 1, counts zeroed): the scan takes it through the FP64 kernel.
+// ---- ingest 2: per variant n3 and the overflow mark, then the exclusive prefix of the listed counts in
+// (range, variant) order.  A variant whose missing genotypes exceed `lim`, or that no longer fits the block's
+// list, is marked (ovf = 1; its counts are skipped): the scan takes it through the FP64 kernel.
+// Five small launches, every pass coalesced: counts per variant; budget in variant order (one workgroup);
+// sums of 1024-element pieces of the (range, variant) sequence; their prefix (one workgroup); the offsets.
+__global__ void __launch_bounds__(256)
+s3_ingest_count_kernel(int M, size_t cap, int lim, const int *__restrict__ cnt, int *__restrict__ n3, uint8_t *__restrict__ ovf)
+{
+	const int v = blockIdx.x * 256 + threadIdx.x;
+	if (v >= M) return;
+	int t = 0;
+#pragma unroll
+	for (int g = 0; g < S3_NR; g++) t += cnt[(size_t)g * cap + v];
+	n3[v] = t;
+	ovf[v] = t > lim ? 1 : 0;
+}
+
+// exclusive prefix over the threads of a 1024-thread workgroup (sh: 1024 values)
+__device__ __forceinline__ unsigned long long s3_block_excl(unsigned long long x, unsigned long long *sh)
+{
+	const int tid = threadIdx.x;
+	sh[tid] = x;
+	__syncthreads();
+	for (int o = 1; o < 1024; o <<= 1) {
+		const unsigned long long y = tid >= o ? sh[tid - o] : 0;
+		__syncthreads();
+		sh[tid] += y;
+		__syncthreads();
+	}
+	const unsigned long long incl = sh[tid];
+	__syncthreads();
+	return incl - x;
+}
+
 __global__ void __launch_bounds__(1024)
-s3_ingest_scan_kernel(int M, size_t cap, int lim, unsigned idx_cap, int *__restrict__ cnt, int *__restrict__ n3,
-	uint8_t *__restrict__ ovf, unsigned *__restrict__ ptr)
+s3_ingest_budget_kernel(int M, unsigned idx_cap, const int *__restrict__ n3, uint8_t *__restrict__ ovf)
 {
 	__shared__ unsigned long long sh[1024];
-	__shared__ unsigned long long carry;
-	const int tid = threadIdx.x;
-	auto block_excl = [&](unsigned long long x) -> unsigned long long {       // exclusive prefix over the threads; sh[1023] + own of last = total
-		sh[tid] = x;
-		__syncthreads();
-		for (int o = 1; o < 1024; o <<= 1) {
-			const unsigned long long y = tid >= o ? sh[tid - o] : 0;
-			__syncthreads();
-			sh[tid] += y;
-			__syncthreads();
-		}
-		const unsigned long long incl = sh[tid];
-		__syncthreads();
-		return incl - x;
-	};
-	// per variant totals; budget in variant order
-	const int per = (M + 1023) / 1024, v0 = tid * per, v1 = min(M, v0 + per);
+	const int tid = threadIdx.x, per = (M + 1023) / 1024, v0 = tid * per, v1 = min(M, v0 + per);
 	unsigned long long mine = 0;
-	for (int v = v0; v < v1; v++) {
-		int t = 0;
-		for (int g = 0; g < S3_NR; g++) t += cnt[(size_t)g * cap + v];
-		n3[v] = t;
-		const bool o = t > lim;
-		ovf[v] = o ? 1 : 0;
-		if (!o) mine += (unsigned long long)t;
-	}
-	unsigned long long base = block_excl(mine);
+	for (int v = v0; v < v1; v++) if (!ovf[v]) mine += (unsigned long long)n3[v];
+	unsigned long long base = s3_block_excl(mine, sh);
 	for (int v = v0; v < v1; v++) {
 		if (ovf[v]) continue;
 		base += (unsigned long long)n3[v];
-		if (base > (unsigned long long)idx_cap) ovf[v] = 1;
+		if (base > (unsigned long long)idx_cap) ovf[v] = 1;     // (and, the sum only growing, every later variant)
 	}
+}
+
+// element e = g M + v of the (range, variant) sequence: its listed count
+__device__ __forceinline__ unsigned s3_listed(size_t e, int M, size_t cap, const int *__restrict__ cnt, const uint8_t *__restrict__ ovf)
+{
+	const size_t g = e / (size_t)M, v = e - g * (size_t)M;
+	return ovf[v] ? 0u : (unsigned)cnt[g * cap + v];
+}
+
+__global__ void __launch_bounds__(256)
+s3_ingest_piece_kernel(int M, size_t cap, const int *__restrict__ cnt, const uint8_t *__restrict__ ovf, unsigned long long *__restrict__ piece)
+{
+	__shared__ unsigned sh[4];
+	const size_t tot = (size_t)S3_NR * M, e0 = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
+	unsigned t = 0;
+#pragma unroll
+	for (int k = 0; k < 4; k++) if (e0 + k < tot) t += s3_listed(e0 + k, M, cap, cnt, ovf);
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
 	__syncthreads();
-	for (int v = v0; v < v1; v++)
-		if (ovf[v]) for (int g = 0; g < S3_NR; g++) cnt[(size_t)g * cap + v] = 0;
+	if (threadIdx.x == 0) piece[blockIdx.x] = (unsigned long long)sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ void __launch_bounds__(1024)
+s3_ingest_piece_scan_kernel(int npiece, unsigned long long *__restrict__ piece)
+{
+	__shared__ unsigned long long sh[1024];
+	const int tid = threadIdx.x, per = (npiece + 1023) / 1024, p0 = tid * per, p1 = min(npiece, p0 + per);
+	unsigned long long mine = 0;
+	for (int p = p0; p < p1; p++) mine += piece[p];
+	unsigned long long base = s3_block_excl(mine, sh);
+	for (int p = p0; p < p1; p++) { const unsigned long long x = piece[p]; piece[p] = base; base += x; }
+}
+
+__global__ void __launch_bounds__(256)
+s3_ingest_ptr_kernel(int M, size_t cap, const int *__restrict__ cnt, const uint8_t *__restrict__ ovf,
+	const unsigned long long *__restrict__ piece, unsigned *__restrict__ ptr)
+{
+	__shared__ unsigned sh[4];
+	const size_t tot = (size_t)S3_NR * M, e0 = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	unsigned c[4], t = 0;
+#pragma unroll
+	for (int k = 0; k < 4; k++) { c[k] = e0 + k < tot ? s3_listed(e0 + k, M, cap, cnt, ovf) : 0u; t += c[k]; }
+	unsigned incl = t;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
+	if (lane == 63) sh[wid] = incl;
 	__syncthreads();
-	// exclusive prefix in (range, variant) order
-	const size_t tot = (size_t)S3_NR * M, per2 = (tot + 1023) / 1024;
-	const size_t e0 = (size_t)tid * per2, e1 = min(tot, e0 + per2);
-	mine = 0;
-	for (size_t e = e0; e < e1; e++) mine += (unsigned long long)cnt[(e / M) * cap + (e % M)];
-	base = block_excl(mine);
-	for (size_t e = e0; e < e1; e++) {
-		ptr[e] = (unsigned)base;
-		base += (unsigned long long)cnt[(e / M) * cap + (e % M)];
-	}
-	if (e1 == tot && e0 < tot) ptr[tot] = (unsigned)base;
-	if (tot == 0 && tid == 0) ptr[0] = 0;
+	unsigned base = (unsigned)piece[blockIdx.x] + incl - t;
+	for (int w = 0; w < wid; w++) base += sh[w];
+#pragma unroll
+	for (int k = 0; k < 4; k++) { if (e0 + k < tot) ptr[e0 + k] = base; base += c[k]; }
+	if (e0 < tot && tot <= e0 + 4) ptr[tot] = base;          // the thread that holds the last element: the end offset
+	if (tot == 0 && blockIdx.x == 0 && threadIdx.x == 0) ptr[0] = 0;
 }
 
 // ---- ingest 3: the lists.  Same walk as ingest 1 over the TILED rows; the sample indices of a variant's

@@ -88,6 +88,7 @@ struct sgx_block {
 	size_t idx_cap = 0;
 	int *n3 = nullptr;           // [cap] missing genotypes per variant (listed or not)
 	uint8_t *ovf = nullptr;      // [cap] 1 = not listed (too many): the scan takes the FP64 kernel for it
+	unsigned long long *piece = nullptr;   // sums of 1024-element pieces of the (range, variant) counts (load-time scratch)
 	hipEvent_t ready = nullptr;  // recorded behind the last load: scans on other streams wait for it
 };
 
@@ -867,7 +868,7 @@ extern "C" void sgx_block_free(sgx_block *b)
 	if (!b) return;
 	(void)hipSetDevice(b->device);
 	(void)hipFree(b->tiles); (void)hipFree(b->cnt); (void)hipFree(b->ptr); (void)hipFree(b->idx);
-	(void)hipFree(b->n3); (void)hipFree(b->ovf);
+	(void)hipFree(b->n3); (void)hipFree(b->ovf); (void)hipFree(b->piece);
 	if (b->ready) (void)hipEventDestroy(b->ready);
 	delete b;
 }
@@ -893,6 +894,7 @@ extern "C" int sgx_block_create(int32_t n_samp, size_t max_variants, int device,
 	if (e == hipSuccess) e = hipMalloc((void **)&b->idx, b->idx_cap * sizeof(unsigned));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->n3, max_variants * sizeof(int));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->ovf, max_variants);
+	if (e == hipSuccess) e = hipMalloc((void **)&b->piece, (((size_t)S3_NR * max_variants + 1023) / 1024 + 1) * sizeof(unsigned long long));
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ready, hipEventDisableTiming);
 	if (e != hipSuccess) { sgx_block_free(b); return fail(e == hipErrorOutOfMemory ? SGX_ENOMEM : SGX_EHIP, "sgx_block_create: %s", hipGetErrorString(e)); }
 	*out = b;
@@ -913,8 +915,13 @@ static int block_put_rows(sgx_block *b, const uint8_t *rows_dev, size_t bpv, siz
 static int block_finish(sgx_block *b, size_t M, hipStream_t st)
 {
 	const size_t lim = 16 * std::max<size_t>(64, (size_t)b->N / 128);
-	hipLaunchKernelGGL(s3_ingest_scan_kernel, dim3(1), dim3(1024), 0, st, (int)M, b->cap, (int)std::min<size_t>(lim, 0x7fffffff), (unsigned)b->idx_cap,
-		b->cnt, b->n3, b->ovf, b->ptr);
+	const size_t tot = (size_t)S3_NR * M;
+	const int npiece = (int)((tot + 1023) / 1024);
+	hipLaunchKernelGGL(s3_ingest_count_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, b->cap, (int)std::min<size_t>(lim, 0x7fffffff), b->cnt, b->n3, b->ovf);
+	hipLaunchKernelGGL(s3_ingest_budget_kernel, dim3(1), dim3(1024), 0, st, (int)M, (unsigned)b->idx_cap, b->n3, b->ovf);
+	hipLaunchKernelGGL(s3_ingest_piece_kernel, dim3((unsigned)npiece), dim3(256), 0, st, (int)M, b->cap, b->cnt, b->ovf, b->piece);
+	hipLaunchKernelGGL(s3_ingest_piece_scan_kernel, dim3(1), dim3(1024), 0, st, npiece, b->piece);
+	hipLaunchKernelGGL(s3_ingest_ptr_kernel, dim3((unsigned)npiece), dim3(256), 0, st, (int)M, b->cap, b->cnt, b->ovf, b->piece, b->ptr);
 	const int nfrag = (int)((M + 15) / 16);
 	hipLaunchKernelGGL(s3_ingest_fill_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, b->tiles, (int)M, b->ntile, b->ovf, b->ptr, b->idx);
 	HIPCHK(hipGetLastError());

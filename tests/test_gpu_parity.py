@@ -390,3 +390,38 @@ def test_scan_sharded_single_rank_rccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_hard_calls_many_short_rows_and_odd_chunks():
+    """Two corners of the host pipeline: (a) RAW / INTEGER hard calls with more than 65 535 rows in one call at
+    a small N (the device pack kernel carries the row in grid.y: the chunk is capped), (b) INTEGER rows with a
+    non-call value at an odd N and an odd number of rows per chunk (the doubles behind the INTEGER rows start
+    on a 16-byte boundary whatever the chunk)."""
+    n, m = 333, 70_000
+    sm, packed = _synthetic_case(n, 1500, "binary", 0.2, seed=5)
+    from saigegds_amd.gds import unpack_dosage_2bit
+    codes = unpack_dosage_2bit(packed, n)
+    reps = -(-m // codes.shape[0])
+    big = np.tile(codes, (reps, 1))[:m]
+    u8 = big.copy()
+    u8[big == 3] = 0xFF
+    ref, ref_valid = _oracle(sm).scan_2bit(packed)
+    with _scanner(sm) as sc:
+        out, valid = sc.scan_u8(u8)                 # one call, 70 000 rows, default chunk size
+        assert sc.stats()["n_variants"] == m
+        k = codes.shape[0]
+        for r in range(reps):
+            lo, hi = r * k, min(m, (r + 1) * k)
+            assert np.array_equal(valid[lo:hi], ref_valid[:hi - lo])
+        assert_table_close(out[:k], valid[:k], ref, ref_valid, what="u8, 70 000 rows")
+        assert np.array_equal(np.nan_to_num(out[:k], nan=-7.0), np.nan_to_num(out[k:2 * k], nan=-7.0))
+        # (b) odd N, odd rows per chunk, one value that is not a call
+        i32 = codes[:601].astype(np.int32)
+        i32[codes[:601] == 3] = -2147483648
+        i32[5, 7] = 4
+        u8b = u8[:601].copy()
+        u8b[5, 7] = 4
+        refb, refb_valid = _oracle(sm).scan_u8(u8b)
+        sc.set_option("pipe_mb", 1)                 # 1 MiB / (12 x 333 B) = 262 rows per chunk: 262 x 333 x 4 is not a multiple of 16
+        outb, validb = sc.scan_i32(i32)
+        assert_table_close(outb, validb, refb, refb_valid, what="i32, odd N, odd chunk, a non-call value")
