@@ -37,7 +37,7 @@ for k in ("n_samples", "variants_per_launch", "n_covariates"):
         meta[k] = int(meta[k])
 kern = {}
 for k in sorted(set(rd) | set(wr)):
-    if "synth" in k or "rocclr" in k:
+    if "synth" in k or "rocclr" in k or k.startswith("s3_ingest"):     # generator, runtime copies, block loading: not part of a step
         continue
     fetch_kb, r32 = rd[k].get("FETCH_SIZE", 0.0), rd[k].get("TCC_EA0_RDREQ_32B_sum", 0.0)
     rdreq = rd[k].get("TCC_EA0_RDREQ_sum", 0.0)
@@ -46,7 +46,7 @@ for k in sorted(set(rd) | set(wr)):
     write_b = wr[k].get("WRITE_SIZE", 0.0) * 1024
     kern[k] = {"launches": nr[k], "read_bytes_per_step": read_b / steps, "write_bytes_per_step": write_b / steps,
                "fetch_doubled": bool(wide)}
-score = [v for k, v in kern.items() if k.startswith("score_mfma_kernel")]
+score = [v for k, v in kern.items() if k.startswith("score3_kernel") or k.startswith("score_mfma_kernel")]
 spa = [v for k, v in kern.items() if k.startswith("spa")]
 out = dict(meta)
 out["steps_profiled"] = steps
