@@ -543,7 +543,7 @@ s3_ingest_fill_kernel(const uint8_t *__restrict__ tiles, int M, int ntile, const
 // on one range (blockIdx % S3_NR): with blocks dealt round-robin over the XCDs an L2 sees two ranges of Q
 // (1/8 of the table).  part: [S3_NR][M][P][2] int64.
 template <int PP>
-__global__ void __launch_bounds__(256, PP <= 16 ? 8 : 4)    /* K <= 7: few enough registers to sit beside score3_kernel's workgroup on a CU */
+__global__ void __launch_bounds__(256, PP <= 16 ? 8 : 7)    /* few enough registers (64 / 72) to sit beside score3_kernel's workgroup on a CU */
 s3_t3_kernel(int M, int P, const long long *__restrict__ Q, const unsigned *__restrict__ ptr, const unsigned *__restrict__ idx,
 	long long *__restrict__ part)
 {
@@ -561,10 +561,10 @@ s3_t3_kernel(int M, int P, const long long *__restrict__ Q, const unsigned *__re
 		unsigned mine[NB];
 #pragma unroll
 		for (int k = 0; k < NB; k++) mine[k] = (e + k * PP + c < e1) ? idx[e + k * PP + c] : 0xFFFFFFFFu;
-		constexpr int UN = 8;                          // gathers issued back to back (PP is a multiple of 8)
+		constexpr int UN = PP <= 16 ? 8 : 4;           // gathers issued back to back (PP is a multiple of 8)
 #pragma unroll
 		for (int k = 0; k < NB; k++)
-#pragma unroll
+#pragma unroll(PP <= 16 ? 2 : 1)
 			for (int j0 = 0; j0 < PP; j0 += UN) {
 				long long q[UN];
 #pragma unroll
