@@ -62,7 +62,16 @@ typedef struct sgx_handle sgx_handle;
 
 /* The list .init_nullmod builds (R/assoc_single.r:28-66) as read by
  * saige_score_test_init (src/saige_main.cpp:106-130).  K x N matrices are
- * column-major, i.e. the K values of sample i are contiguous at [K*i]. */
+ * column-major, i.e. the K values of sample i are contiguous at [K*i].
+ *
+ * t_XXVX_inv and XV are part of the reference's list and are accepted here so
+ * that the caller passes the list as it is, but the scan does not read them:
+ * both reference branches (saige_main.cpp:237-262 sparse, :263-292 dense) are
+ * computed from t_X, t_XVX_inv_XV, XVX and S_a.  They may be
+ * NULL.  With SAIGEHIP_CHECK_MODEL=1 in the environment sgx_init holds them
+ * against t_X / t_XVX_inv_XV (XV = V t_X, t_XVX_inv_XV = V t_XXVX_inv with one
+ * weight V_i per sample, 1e-8) and returns SGX_EINVAL naming the first entry
+ * that disagrees -- for callers who assemble the arrays themselves. */
 typedef struct sgx_model {
 	int32_t n_samp;              /* N  = length(y)                  :117 */
 	int32_t n_coeff;             /* K  = nrow(XV)                   :118 */
@@ -78,8 +87,8 @@ typedef struct sgx_model {
 	const double *mu;            /* N                               :121 */
 	const double *y_mu;          /* N   y - mu                      :122 */
 	const double *mu2;           /* N   mu*(1-mu)                   :123 */
-	const double *t_XXVX_inv;    /* K x N                           :124 */
-	const double *XV;            /* K x N                           :125 */
+	const double *t_XXVX_inv;    /* K x N   NOT READ by the scan    :124 */
+	const double *XV;            /* K x N   NOT READ by the scan    :125 */
 	const double *t_XVX_inv_XV;  /* K x N                           :126 */
 	const double *XVX;           /* K x K                           :127 */
 	const double *t_X;           /* K x N                           :128 */

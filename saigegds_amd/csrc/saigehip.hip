@@ -303,6 +303,36 @@ static int alloc_workspace(sgx_handle *h)
 	return SGX_OK;
 }
 
+// Diagnostic of sgx_init (SAIGEHIP_CHECK_MODEL=1).  R/assoc_single.r:28-48 builds, per sample i with no-K weight
+// V_i,  XV[:,i] = V_i t_X[:,i]  and  t_XVX_inv_XV[:,i] = V_i t_XXVX_inv[:,i]:  V_i is read off the largest
+// entry of t_X[:,i] and both relations are held to 1e-8 of the column's largest entry.
+static int check_model_consistency(const sgx_model *m)
+{
+	const int N = m->n_samp, K = m->n_coeff;
+	if (!m->t_XXVX_inv || !m->XV)
+		return fail(SGX_EINVAL, "sgx_init: SAIGEHIP_CHECK_MODEL needs t_XXVX_inv and XV");
+	for (int i = 0; i < N; i++) {
+		const double *x = m->t_X + (size_t)i * K, *xv = m->XV + (size_t)i * K,
+			*a = m->t_XXVX_inv + (size_t)i * K, *av = m->t_XVX_inv_XV + (size_t)i * K;
+		int k0 = 0;
+		double sx = 0, sa = 0;
+		for (int k = 0; k < K; k++) {
+			if (std::fabs(x[k]) > std::fabs(x[k0])) k0 = k;
+			sx = std::max(sx, std::fabs(xv[k])); sa = std::max(sa, std::fabs(av[k]));
+		}
+		if (x[k0] == 0) continue;
+		const double V = xv[k0] / x[k0];
+		for (int k = 0; k < K; k++) {
+			if (std::fabs(xv[k] - V * x[k]) > 1e-8 * sx)
+				return fail(SGX_EINVAL, "sgx_init: XV[%d,%d] = %g is not V t_X = %g", k, i, xv[k], V * x[k]);
+			if (std::fabs(av[k] - V * a[k]) > 1e-8 * sa)
+				return fail(SGX_EINVAL, "sgx_init: t_XVX_inv_XV[%d,%d] = %g is not V t_XXVX_inv = %g",
+					k, i, av[k], V * a[k]);
+		}
+	}
+	return SGX_OK;
+}
+
 extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 {
 	if (!m || !out) return fail(SGX_EINVAL, "sgx_init: NULL argument");
@@ -315,6 +345,11 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 		return fail(SGX_EINVAL, "sgx_init: invalid trait %d", m->trait);
 	if (!m->y || !m->mu || !m->y_mu || !m->mu2 || !m->t_XVX_inv_XV || !m->t_X || !m->XVX || !m->S_a)
 		return fail(SGX_EINVAL, "sgx_init: NULL model array");
+	// t_XXVX_inv and XV are not read by the scan (the carrier formulation needs t_X, t_XVX_inv_XV, XVX and
+	// S_a only).  SAIGEHIP_CHECK_MODEL=1 holds them against the arrays that ARE read, so that a
+	// caller whose five K x N arrays do not belong together is told instead of getting one branch's algebra.
+	{ const char *e = getenv("SAIGEHIP_CHECK_MODEL");
+	  if (e && e[0] == '1') { int rc = check_model_consistency(m); if (rc) return rc; } }
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
 		return fail(SGX_ENODEV, "sgx_init: no HIP device available");

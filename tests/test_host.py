@@ -37,6 +37,30 @@ def test_init_rejects_bad_models_without_gpu():
     assert b"n_coeff" in L.sgx_last_error()
 
 
+def test_model_consistency_diagnostic(monkeypatch):
+    """SAIGEHIP_CHECK_MODEL=1: the two arrays of the list the scan does not read (t_XXVX_inv, XV) are held
+    against the ones it reads; both golden models pass (the call then gets as far as looking for a device),
+    a model whose XV belongs to other weights is refused by name."""
+    import torch
+    from saigegds_amd import _lib
+    from saigegds_amd.nullmod import init_nullmod
+    monkeypatch.setenv("SAIGEHIP_CHECK_MODEL", "1")
+    for fn in ("saige_model.npz", "saige_model_quant.npz"):
+        mod = load_null_model(fn)
+        sm = init_nullmod(mod, np.arange(len(mod.sample_id)), 0, 0, 1, 0.05, 1.0)
+        if not torch.cuda.is_available():
+            with pytest.raises(_lib.SgxError, match="no HIP device") as e:
+                _lib.Scanner(sm)
+            assert e.value.code == -4
+        else:
+            _lib.Scanner(sm).close()
+        sm.XV = sm.XV.copy()
+        sm.XV[7, 1] *= 1.001
+        with pytest.raises(_lib.SgxError, match=r"XV\[1,7\]") as e:
+            _lib.Scanner(sm)
+        assert e.value.code == -1
+
+
 def test_init_nullmod_matches_reference_layout():
     """.init_nullmod (R/assoc_single.r:17-67): shapes, orientation, derived terms."""
     from saigegds_amd.nullmod import init_nullmod, ModelError
