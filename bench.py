@@ -167,6 +167,9 @@ def measure(case, steps, warmup, lanes, world=1, dist=None, rehearse=False):
     sc = case.sc
     lanes = lanes if case.pool >= 2 else 1            # two steps in flight need two result buffers
     sc.set_option("lanes", lanes)
+    for kv in filter(None, os.environ.get("SGX_BENCH_OPTS", "").split(",")):     # experiments: "name=value,..."
+        k, v = kv.split("=")
+        sc.set_option(k, int(v))
 
     def barrier():
         torch.cuda.synchronize()
@@ -216,6 +219,9 @@ def measure(case, steps, warmup, lanes, world=1, dist=None, rehearse=False):
 
 
 def main():
+    if os.environ.get("SGX_BENCH_WATCHDOG"):      # a run that hangs says where: Python stacks to stderr, then exit
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["SGX_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)

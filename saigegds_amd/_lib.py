@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsaigehip.so")
+LIB_PATH = os.environ.get("SAIGEHIP_LIB") or os.path.join(_HERE, "libsaigehip.so")   # (the override: A/B runs of two builds)
 
 EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",

@@ -11,6 +11,9 @@ struct RowsRef {
 	const uint8_t *base;
 	size_t bpv;       // row-major: bytes per row
 	int ntile;        // tiled: 256-sample tiles per row; 0 = row-major
+	// genotype blocks: the carrier lists of the rare variants (kern_score3.h, s3_ingest_clist_kernel); else null
+	const unsigned *cptr, *cidx;
+	const uint8_t *corient;
 };
 // byte offset of piece p of row j
 __device__ __forceinline__ size_t rr_piece(const RowsRef &rr, size_t j, size_t p)

@@ -331,10 +331,12 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 // ---- ingest 1: transpose to tiles, count the missing codes per (sample range, variant).
 // One wave per fragment of 16 variants; lane (r, kg) moves the 16 B of variant 16 frag + r that cover samples
 // 64 kg .. 64 kg + 63 of the tile.  Codes of samples >= N are cleared (a stray 3 there must not be listed).
+// Also per variant: the number of non-zero codes and of codes 2 (nzv, n2v: what decides whether the variant gets
+// a carrier list, s3_ingest_clist_kernel).
 // rows: M rows of bpv bytes, bpv >= 64 ntile, 16-byte aligned.
 __global__ void __launch_bounds__(256)
 s3_ingest_tile_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int M, int ntile,
-	uint8_t *__restrict__ tiles, int *__restrict__ cnt, size_t cap)
+	uint8_t *__restrict__ tiles, int *__restrict__ cnt, size_t cap, int *__restrict__ nzv, int *__restrict__ n2v)
 {
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 	const int frag = blockIdx.x * 4 + wid, nfrag = (M + 15) / 16;
@@ -344,7 +346,7 @@ s3_ingest_tile_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int M
 	const uint8_t *src = rows + (size_t)(live ? v : 0) * bpv + kg * 16;
 	uint8_t *dst = tiles + (size_t)frag * ntile * 1024 + s3_dma_lane(lane) * 16;
 	constexpr int UN = 4;
-	int rg = 0, tend = s3_range_t0(1, ntile), c = 0;
+	int rg = 0, tend = s3_range_t0(1, ntile), c = 0, cz = 0, c2 = 0;
 	for (int t0 = 0; t0 < ntile; t0 += UN) {
 		uint4 w[UN];
 #pragma unroll
@@ -369,6 +371,8 @@ s3_ingest_tile_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int M
 				const int keep = N - s0 - 16 * u;
 				d[u] &= (keep >= 16) ? 0xFFFFFFFFu : ((keep <= 0) ? 0u : ((1u << (2 * keep)) - 1u));
 				c += __popc(d[u] & (d[u] >> 1) & 0x55555555u);
+				cz += __popc((d[u] | (d[u] >> 1)) & 0x55555555u);
+				c2 += __popc(~d[u] & (d[u] >> 1) & 0x55555555u);
 			}
 			*reinterpret_cast<uint4 *>(dst + (size_t)t * 1024) = make_uint4(d[0], d[1], d[2], d[3]);
 		}
@@ -379,6 +383,9 @@ s3_ingest_tile_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int M
 		if (kg == 0 && live) cnt[(size_t)rg * cap + v] = tot;
 		c = 0; rg++;
 	}
+	cz += __shfl_xor(cz, 16, 64); cz += __shfl_xor(cz, 32, 64);
+	c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
+	if (kg == 0 && live) { nzv[v] = cz; n2v[v] = c2; }
 }
 
 // ---- ingest 2: per variant n3 and the overflow mark, then the exclusive prefix of the listed counts in
@@ -463,6 +470,42 @@ s3_ingest_piece_scan_kernel(int npiece, unsigned long long *__restrict__ piece)
 	for (int p = p0; p < p1; p++) { const unsigned long long x = piece[p]; piece[p] = base; base += x; }
 }
 
+// ---- carrier lists of the rare variants (the input of the per-variant SPA kernels, kern_spa4.h): a variant
+// with at most `lim` carriers -- non-zero codes where the alt allele is the minor one, codes other than 2 where
+// the scan will flip it (make_head: AF > 0.5, from the same integer counts) -- gets its carriers listed in
+// ascending sample order at cidx[cptr[v] .. cptr[v + 1]) as sample | code << 30; corient[v] = 1 / 2 says which
+// orientation the list is for, 0 = no list (too many carriers, or the block's list is full: the kernels then
+// scan the variant's row as they do for row-major input).  One workgroup: the offsets in variant order.
+__global__ void __launch_bounds__(1024)
+s3_ingest_clist_kernel(int M, int N, int lim, unsigned cidx_cap, const int *__restrict__ nzv, const int *__restrict__ n2v,
+	const int *__restrict__ n3, unsigned *__restrict__ cptr, uint8_t *__restrict__ corient)
+{
+	__shared__ unsigned long long sh[1024];
+	const int tid = threadIdx.x, per = (M + 1023) / 1024, v0 = tid * per, v1 = min(M, v0 + per);
+	auto listed = [&](int v, int &orient) -> int {
+		const int nz = nzv[v], n2 = n2v[v], m3 = n3[v];
+		const long long AC = (long long)(nz - n2 - m3) + 2ll * n2;
+		const bool minus = (double)AC / (2.0 * (double)(N - m3)) > 0.5;      // make_head (dev_common.h)
+		const int nnz = minus ? N - n2 : nz;
+		orient = (N - m3 > 0 && nnz <= lim) ? (minus ? 2 : 1) : 0;
+		return orient ? nnz : 0;
+	};
+	unsigned long long mine = 0;
+	for (int v = v0; v < v1; v++) { int o; mine += (unsigned long long)listed(v, o); }
+	unsigned long long base = s3_block_excl(mine, sh);
+	for (int v = v0; v < v1; v++) {
+		int o;
+		const int n = listed(v, o);
+		const bool fits = base + (unsigned long long)n <= (unsigned long long)cidx_cap;
+		// (a full list: this variant and, the sum only growing, the later ones that do not fit go unlisted;
+		// their offsets stay valid, empty ranges)
+		cptr[v] = (unsigned)min(base, (unsigned long long)cidx_cap);
+		corient[v] = fits ? (uint8_t)o : (uint8_t)0;
+		if (fits) base += (unsigned long long)n;
+	}
+	if (tid == 1023) cptr[M] = (unsigned)min(base, (unsigned long long)cidx_cap);
+}
+
 __global__ void __launch_bounds__(256)
 s3_ingest_ptr_kernel(int M, size_t cap, const int *__restrict__ cnt, const uint8_t *__restrict__ ovf,
 	const unsigned long long *__restrict__ piece, unsigned *__restrict__ ptr)
@@ -487,20 +530,24 @@ s3_ingest_ptr_kernel(int M, size_t cap, const int *__restrict__ cnt, const uint8
 }
 
 // ---- ingest 3: the lists.  Same walk as ingest 1 over the TILED rows; the sample indices of a variant's
-// missing genotypes of range g go to idx[ptr[g M + v] ..), ascending.
+// missing genotypes of range g go to idx[ptr[g M + v] ..), ascending; the carriers of a variant that
+// s3_ingest_clist_kernel gave a list to cidx[cptr[v] ..) as sample | code << 30, ascending.
 __global__ void __launch_bounds__(256)
-s3_ingest_fill_kernel(const uint8_t *__restrict__ tiles, int M, int ntile, const uint8_t *__restrict__ ovf,
-	const unsigned *__restrict__ ptr, unsigned *__restrict__ idx)
+s3_ingest_fill_kernel(const uint8_t *__restrict__ tiles, int N, int M, int ntile, const uint8_t *__restrict__ ovf,
+	const unsigned *__restrict__ ptr, unsigned *__restrict__ idx,
+	const uint8_t *__restrict__ corient, const unsigned *__restrict__ cptr, unsigned *__restrict__ cidx)
 {
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 	const int frag = blockIdx.x * 4 + wid, nfrag = (M + 15) / 16;
 	if (frag >= nfrag) return;
 	const int r = lane & 15, kg = lane >> 4, v = frag * 16 + r;
 	const bool live = v < M && !ovf[v];
+	const int orient = v < M ? corient[v] : 0;
+	const uint32_t zx = orient == 2 ? 0xAAAAAAAAu : 0u;      // flipped: the carriers are the codes other than 2
 	const uint8_t *src = tiles + (size_t)frag * ntile * 1024 + s3_dma_lane(lane) * 16;
 	constexpr int UN = 4;
 	int rg = -1, tend = 0;
-	unsigned off = 0;
+	unsigned off = 0, coff = orient ? cptr[v] : 0u;
 	for (int t0 = 0; t0 < ntile; t0 += UN) {
 		uint4 w[UN];
 #pragma unroll
@@ -514,22 +561,47 @@ s3_ingest_fill_kernel(const uint8_t *__restrict__ tiles, int M, int ntile, const
 			if (t >= ntile) break;
 			while (t >= tend) { rg++; tend = s3_range_t0(rg + 1, ntile); off = live ? ptr[(size_t)rg * M + v] : 0u; }
 			const uint32_t d[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
-			uint32_t m[4];
-			int c = 0;
-#pragma unroll
-			for (int u = 0; u < 4; u++) { m[u] = live ? (d[u] & (d[u] >> 1) & 0x55555555u) : 0u; c += __popc(m[u]); }
-			if (!__ballot(c != 0)) continue;
-			// exclusive prefix over the four kg lanes of the variant
-			const int c0 = __shfl(c, r, 64), c1 = __shfl(c, r + 16, 64), c2 = __shfl(c, r + 32, 64), c3 = __shfl(c, r + 48, 64);
-			unsigned o = off + (kg > 0 ? c0 : 0) + (kg > 1 ? c1 : 0) + (kg > 2 ? c2 : 0);
-			off += (unsigned)(c0 + c1 + c2 + c3);
+			uint32_t m[4], z[4];
+			int c = 0, cc = 0;
+			const int s0 = t * 256 + kg * 64;
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
-				uint32_t mm = m[u];
-				while (mm) {
-					const int b = __ffs(mm) - 1;
-					mm &= mm - 1;
-					idx[o++] = (unsigned)(t * 256 + kg * 64 + u * 16 + (b >> 1));
+				m[u] = live ? (d[u] & (d[u] >> 1) & 0x55555555u) : 0u;
+				c += __popc(m[u]);
+				const int keep = N - s0 - 16 * u;     // (the padding samples hold code 0: carriers of a flipped variant otherwise)
+				const uint32_t km = (keep >= 16) ? 0xFFFFFFFFu : ((keep <= 0) ? 0u : ((1u << (2 * keep)) - 1u));
+				const uint32_t x = (d[u] ^ zx) & km;
+				z[u] = orient ? ((x | (x >> 1)) & 0x55555555u) : 0u;
+				cc += __popc(z[u]);
+			}
+			if (!__ballot((c | cc) != 0)) continue;
+			// exclusive prefix over the four kg lanes of the variant
+			if (__ballot(c != 0)) {
+				const int c0 = __shfl(c, r, 64), c1 = __shfl(c, r + 16, 64), c2 = __shfl(c, r + 32, 64), c3 = __shfl(c, r + 48, 64);
+				unsigned o = off + (kg > 0 ? c0 : 0) + (kg > 1 ? c1 : 0) + (kg > 2 ? c2 : 0);
+				off += (unsigned)(c0 + c1 + c2 + c3);
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					uint32_t mm = m[u];
+					while (mm) {
+						const int b = __ffs(mm) - 1;
+						mm &= mm - 1;
+						idx[o++] = (unsigned)(t * 256 + kg * 64 + u * 16 + (b >> 1));
+					}
+				}
+			}
+			if (__ballot(cc != 0)) {
+				const int c0 = __shfl(cc, r, 64), c1 = __shfl(cc, r + 16, 64), c2 = __shfl(cc, r + 32, 64), c3 = __shfl(cc, r + 48, 64);
+				unsigned o = coff + (kg > 0 ? c0 : 0) + (kg > 1 ? c1 : 0) + (kg > 2 ? c2 : 0);
+				coff += (unsigned)(c0 + c1 + c2 + c3);
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					uint32_t mm = z[u];
+					while (mm) {
+						const int b = __ffs(mm) - 1;
+						mm &= mm - 1;
+						cidx[o++] = (unsigned)(s0 + u * 16 + (b >> 1)) | (((d[u] >> b) & 3u) << 30);
+					}
 				}
 			}
 		}

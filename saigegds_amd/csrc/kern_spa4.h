@@ -44,11 +44,17 @@
 //                 the cutoff exit (SPATest.cpp:319-321), both root searches (root_feed / root_step of
 //                 kern_spa2.h, fed from the series), tail probabilities, SE, the output row
 
-// waves of spa4_moments' one workgroup per CU: 12 = three per SIMD at 168 registers (measured at C3:
-// 8 waves 1.74 ms for the whole stage, 12 waves 1.57; 16 would need 128 registers and spill).  With many
-// covariates a wave's state (c[K], a table row per carrier in flight) no longer fits 168: K = 13 ran
-// 2.56 ms at 8 waves and 3.24 at 12.
-__host__ __device__ constexpr int spa4_waves(int K) { return K <= 8 ? 12 : 8; }
+// waves of spa4_moments' one workgroup per CU: 8 = two per SIMD at 168 registers.  Alone, 12 waves are faster
+// at K <= 8 (C3: 0.87 ms against 0.95 for tier A; 16 would need 128 registers and spill), but three waves of
+// 168 registers leave a SIMD nothing: with two, the small kernels of the step in flight on the other lane
+// (sparse pass, reduction, epilogue, solves) find room beside the pass instead of waiting for it, and the scan
+// as a whole is ~2 % faster on two lanes (same box, C3: 2.55 -> 2.50 ms per step; K = 5: 3.42 -> 3.29).  With
+// many covariates a wave's state (c[K], a table row per carrier in flight) does not fit 168 registers at
+// three waves anyway: K = 13 ran 2.56 ms at 8 waves and 3.24 at 12.
+#ifndef SPA4_WAVES_LOWK
+#define SPA4_WAVES_LOWK 8
+#endif
+__host__ __device__ constexpr int spa4_waves(int K) { return K <= 8 ? SPA4_WAVES_LOWK : 8; }
 #define SPA4_NCA 12              /* cumulants carried for the variants of tier A (small g t: most carriers) */
 #define SPA4_NCB SPA4_NC         /* ... of tier B */
 #define SPA4_NSMAX (SPA4_NC + 5) /* partial sums per (variant, segment) of the wider tier */
@@ -788,7 +794,7 @@ __global__ void __launch_bounds__(BLOCK)
 spa5_kernel(RowsRef rr, DevModel md, const SpaRec *__restrict__ recs,
 	int *__restrict__ counters, const int *__restrict__ todo, int *__restrict__ todo_next, int *__restrict__ cursor,
 	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8, int force_dense, int force_exact,
-	size_t lds_row_bytes)
+	size_t lds_row_bytes, int only, size_t wg_stride, int nslot)
 {
 	constexpr int KP = (K + 2) & ~1, NW = BLOCK / WAVE;
 	extern __shared__ __attribute__((aligned(16))) uint8_t fill_smem[];
@@ -799,9 +805,12 @@ spa5_kernel(RowsRef rr, DevModel md, const SpaRec *__restrict__ recs,
 	__shared__ int sh_vi, sh_v;
 	__shared__ SpaRec sh_rec;
 	const int N = md.N, tid = threadIdx.x, lane = tid & (WAVE - 1), wid = tid / WAVE;
-	double2 *glist = reinterpret_cast<double2 *>(scratch + (size_t)blockIdx.x * spa5_wg_bytes(N));
+	// only = 2: the block's carrier lists (rr.cptr) are not used (diagnostic: every variant scans its row); 0: used
+	double2 *glist = reinterpret_cast<double2 *>(scratch + (size_t)blockIdx.x * wg_stride);
 	uint32_t *ilist = reinterpret_cast<uint32_t *>(glist + (((size_t)N + 63) & ~(size_t)63));
-	const int ntodo = counters[MODE == 0 ? 3 : 4];
+	// length of the list: counters[3] / [4], or a copy taken when the list was complete (a launch that runs
+	// beside a kernel that still appends to it)
+	const int ntodo = counters[nslot];
 	// pieces of 64 samples: a uint4 of a packed row, or 64 dosages
 	const int nvec = INPUT == IN_2BIT ? (int)(min((size_t)((N + 63) >> 6) * 16, rr_row_bytes(rr)) / 16) : (N + 63) >> 6;
 	const int per = ((nvec + NW - 1) / NW + WAVE - 1) & ~(WAVE - 1);          // pieces per wave, whole wave steps
@@ -835,92 +844,99 @@ spa5_kernel(RowsRef rr, DevModel md, const SpaRec *__restrict__ recs,
 		auto row_piece = [&](int p) -> uint4 { return *reinterpret_cast<const uint4 *>(rr.base + rr_piece(rr, (size_t)r.j, (size_t)p)); };
 		const uint32_t zx = r.minus ? 0xAAAAAAAAu : 0u;
 		const double lut0 = r.lut[0], lut1 = r.lut[1], lut2 = r.lut[2], lut3 = r.lut[3];
-		// ---- index list: sample | code << 30, ascending.  Wave w owns pieces [w per, (w+1) per).
-		// ww/z: codes and carrier bits of piece p (2-bit rows); dosage rows: z[0], z[1] = a 64-bit mask of
-		// the piece's non-zero dosages, bit s = sample 64 p + s
-		// 2-bit rows that fit go through LDS: one streaming copy with many loads in flight instead of two
-		// latency-bound passes over global memory (rows_lds: dynamic shared memory of nvec uint4, or none)
-		const bool staged = INPUT == IN_2BIT && lds_row_bytes >= (size_t)nvec * 16;
-		if (staged) {
-			constexpr int UN = 8;
-			for (int p0 = tid; p0 < nvec; p0 += UN * BLOCK) {
-				uint4 t[UN];
-#pragma unroll
-				for (int j = 0; j < UN; j++) { const int p = p0 + j * BLOCK; t[j] = p < nvec ? row_piece(p) : make_uint4(0u, 0u, 0u, 0u); }
-#pragma unroll
-				for (int j = 0; j < UN; j++) { const int p = p0 + j * BLOCK; if (p < nvec) rows_lds[p] = t[j]; }
+		// The block's carrier list of the variant, when it has one for this orientation: sample | code << 30 in
+		// ascending order, r.nnz entries -- what the three phases below build from the row otherwise.
+		const bool listed = INPUT == IN_2BIT && only != 2 && rr.cptr != nullptr && rr.corient[r.j] == (r.minus ? 2 : 1);
+		const uint32_t *il = listed ? rr.cidx + rr.cptr[r.j] : ilist;
+		int nnz = listed ? r.nnz : 0;
+		if (!listed) {
+			// ---- index list: sample | code << 30, ascending.  Wave w owns pieces [w per, (w+1) per).
+			// ww/z: codes and carrier bits of piece p (2-bit rows); dosage rows: z[0], z[1] = a 64-bit mask of
+			// the piece's non-zero dosages, bit s = sample 64 p + s
+			// 2-bit rows that fit go through LDS: one streaming copy with many loads in flight instead of two
+			// latency-bound passes over global memory (rows_lds: dynamic shared memory of nvec uint4, or none)
+			const bool staged = INPUT == IN_2BIT && lds_row_bytes >= (size_t)nvec * 16;
+			if (staged) {
+				constexpr int UN = 8;
+				for (int p0 = tid; p0 < nvec; p0 += UN * BLOCK) {
+					uint4 t[UN];
+	#pragma unroll
+					for (int j = 0; j < UN; j++) { const int p = p0 + j * BLOCK; t[j] = p < nvec ? row_piece(p) : make_uint4(0u, 0u, 0u, 0u); }
+	#pragma unroll
+					for (int j = 0; j < UN; j++) { const int p = p0 + j * BLOCK; if (p < nvec) rows_lds[p] = t[j]; }
+				}
+				__syncthreads();
 			}
+			SPA5_T(0);
+			auto masks = [&](int p, uint32_t (&ww)[4], uint32_t (&z)[4]) -> int {
+				int cnt = 0;
+				if (INPUT == IN_2BIT) {
+					uint4 w = make_uint4(0u, 0u, 0u, 0u);
+					if (p < nvec) w = staged ? rows_lds[p] : row_piece(p);
+					ww[0] = w.x; ww[1] = w.y; ww[2] = w.z; ww[3] = w.w;
+	#pragma unroll
+					for (int k = 0; k < 4; k++) { z[k] = nz_fields((ww[k] ^ zx) & keep_mask(N - p * 64 - 16 * k)); cnt += __popc(z[k]); }
+				} else {
+					z[0] = z[1] = z[2] = z[3] = 0;
+					if (p < nvec) {
+						for (int s2 = 0; s2 < 64; s2++) {
+							const int i = p * 64 + s2;
+							if (i < N && load_dosage<INPUT>(rr, i, r) != 0) { z[s2 >> 5] |= 1u << (s2 & 31); cnt++; }
+						}
+					}
+				}
+				return cnt;
+			};
+			int cnt_w = 0;
+			for (int it = 0; it < per; it += WAVE) {
+				uint32_t ww[4], z[4];
+				cnt_w += masks(wid * per + it + lane, ww, z);
+			}
+			cnt_w = wave_sum_i(cnt_w);
+			if (lane == 0) shi[wid] = cnt_w;
 			__syncthreads();
-		}
-		SPA5_T(0);
-		auto masks = [&](int p, uint32_t (&ww)[4], uint32_t (&z)[4]) -> int {
-			int cnt = 0;
-			if (INPUT == IN_2BIT) {
-				uint4 w = make_uint4(0u, 0u, 0u, 0u);
-				if (p < nvec) w = staged ? rows_lds[p] : row_piece(p);
-				ww[0] = w.x; ww[1] = w.y; ww[2] = w.z; ww[3] = w.w;
-#pragma unroll
-				for (int k = 0; k < 4; k++) { z[k] = nz_fields((ww[k] ^ zx) & keep_mask(N - p * 64 - 16 * k)); cnt += __popc(z[k]); }
-			} else {
-				z[0] = z[1] = z[2] = z[3] = 0;
-				if (p < nvec) {
-					for (int s2 = 0; s2 < 64; s2++) {
-						const int i = p * 64 + s2;
-						if (i < N && load_dosage<INPUT>(rr, i, r) != 0) { z[s2 >> 5] |= 1u << (s2 & 31); cnt++; }
+			int o_w = 0;
+	#pragma unroll
+			for (int w = 0; w < NW; w++) { if (w < wid) o_w += shi[w]; nnz += shi[w]; }
+			SPA5_T(1);
+			for (int it = 0; it < per; it += WAVE) {
+				uint32_t ww[4], z[4];
+				const int p = wid * per + it + lane;
+				const int cnt = masks(p, ww, z);
+				if (!__ballot(cnt != 0)) continue;
+				int incl = cnt;
+	#pragma unroll
+				for (int o = 1; o < WAVE; o <<= 1) {
+					const int up = __shfl_up(incl, o, WAVE);
+					if (lane >= o) incl += up;
+				}
+				int o2 = o_w + incl - cnt;
+				o_w += __shfl(incl, WAVE - 1, WAVE);
+				if (INPUT == IN_2BIT) {
+	#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						uint32_t zz = z[k];
+						while (zz) {
+							const int b = __ffs(zz) - 1;
+							zz &= zz - 1;
+							ilist[o2++] = (uint32_t)(p * 64 + 16 * k + (b >> 1)) | (((ww[k] >> b) & 3u) << 30);
+						}
+					}
+				} else {
+	#pragma unroll
+					for (int k = 0; k < 2; k++) {
+						uint32_t zz = z[k];
+						while (zz) {
+							const int b = __ffs(zz) - 1;
+							zz &= zz - 1;
+							ilist[o2++] = (uint32_t)(p * 64 + 32 * k + b);
+						}
 					}
 				}
 			}
-			return cnt;
-		};
-		int cnt_w = 0;
-		for (int it = 0; it < per; it += WAVE) {
-			uint32_t ww[4], z[4];
-			cnt_w += masks(wid * per + it + lane, ww, z);
+			__syncthreads();                         // publishes the index list to the workgroup
+			SPA5_T(2);
 		}
-		cnt_w = wave_sum_i(cnt_w);
-		if (lane == 0) shi[wid] = cnt_w;
-		__syncthreads();
-		int o_w = 0, nnz = 0;
-#pragma unroll
-		for (int w = 0; w < NW; w++) { if (w < wid) o_w += shi[w]; nnz += shi[w]; }
-		SPA5_T(1);
-		for (int it = 0; it < per; it += WAVE) {
-			uint32_t ww[4], z[4];
-			const int p = wid * per + it + lane;
-			const int cnt = masks(p, ww, z);
-			if (!__ballot(cnt != 0)) continue;
-			int incl = cnt;
-#pragma unroll
-			for (int o = 1; o < WAVE; o <<= 1) {
-				const int up = __shfl_up(incl, o, WAVE);
-				if (lane >= o) incl += up;
-			}
-			int o2 = o_w + incl - cnt;
-			o_w += __shfl(incl, WAVE - 1, WAVE);
-			if (INPUT == IN_2BIT) {
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					uint32_t zz = z[k];
-					while (zz) {
-						const int b = __ffs(zz) - 1;
-						zz &= zz - 1;
-						ilist[o2++] = (uint32_t)(p * 64 + 16 * k + (b >> 1)) | (((ww[k] >> b) & 3u) << 30);
-					}
-				}
-			} else {
-#pragma unroll
-				for (int k = 0; k < 2; k++) {
-					uint32_t zz = z[k];
-					while (zz) {
-						const int b = __ffs(zz) - 1;
-						zz &= zz - 1;
-						ilist[o2++] = (uint32_t)(p * 64 + 32 * k + b);
-					}
-				}
-			}
-		}
-		__syncthreads();                         // publishes the index list to the workgroup
-		SPA5_T(2);
 		// ---- (adj, mu) list + carrier sums (kern_spa2.h)
 		const double inv = 1 / sqrt(r.AC2);
 		double c[K];
@@ -934,7 +950,7 @@ spa5_kernel(RowsRef rr, DevModel md, const SpaRec *__restrict__ recs,
 			uint32_t e[UNG];
 			double xv[UNG][KP];
 #pragma unroll
-			for (int j = 0; j < UNG; j++) e[j] = (k0 + j * BLOCK < nnz) ? ilist[k0 + j * BLOCK] : 0u;
+			for (int j = 0; j < UNG; j++) e[j] = (k0 + j * BLOCK < nnz) ? il[k0 + j * BLOCK] : 0u;
 #pragma unroll
 			for (int j = 0; j < UNG; j++) {
 				const double *x = md.XM + (size_t)(e[j] & 0x3FFFFFFFu) * KP;

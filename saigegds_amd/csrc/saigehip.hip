@@ -89,6 +89,12 @@ struct sgx_block {
 	int *n3 = nullptr;           // [cap] missing genotypes per variant (listed or not)
 	uint8_t *ovf = nullptr;      // [cap] 1 = not listed (too many): the scan takes the FP64 kernel for it
 	unsigned long long *piece = nullptr;   // sums of 1024-element pieces of the (range, variant) counts (load-time scratch)
+	// carrier lists of the rare variants (at most SPA5_NNZ carriers): what the per-variant SPA kernels walk
+	int *nzv = nullptr, *n2v = nullptr;    // [cap] non-zero codes / codes 2 per variant (load-time scratch)
+	unsigned *cptr = nullptr;    // [cap + 1] start of a variant's list in cidx
+	unsigned *cidx = nullptr;    // sample | code << 30, ascending per variant
+	size_t cidx_cap = 0;
+	uint8_t *corient = nullptr;  // [cap] 0 no list, 1 list of the non-zero codes, 2 of the codes other than 2 (AF > 0.5)
 	hipEvent_t ready = nullptr;  // recorded behind the last load: scans on other streams wait for it
 };
 
@@ -298,7 +304,7 @@ static int alloc_workspace(sgx_handle *h)
 		// short (128-thread workgroups, see the launch), else one
 		h->nwg5 = (size_t)((N + 63) / 64) * 16 <= 32 * 1024 ? h->n_cu * 4 : h->n_cu;
 		HIPCHK(hipMalloc((void **)&h->scr5, (size_t)h->nwg5 * spa5_wg_bytes(N)));
-		HIPCHK(hipMalloc((void **)&h->cur5, 4 * sizeof(int)));   // [0], [1] spa5_kernel queues; [2], [3] spa4_moments' item queue
+		HIPCHK(hipMalloc((void **)&h->cur5, 8 * sizeof(int)));   // [0], [1] spa5_kernel queues; [2], [3] spa4_moments' item queue; [4], [5] spa5_kernel on the blocks' lists
 	}
 	return SGX_OK;
 }
@@ -672,8 +678,6 @@ static int launch_spa(sgx_handle *h, RowsRef rr, size_t M, double *out8)
 			const int nround = (int)((M + h->vcap4 - 1) / h->vcap4);                         \
 			const int btop = (int)(2 * M);                                                   \
 			const dim3 gsolve((unsigned)std::min((h->vcap4 + 3) / 4, 4 * h->n_cu));   /* a wave per variant, grid-stride */ \
-			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCA, 0, rd);                \
-			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCB, 1, rd);                \
 			/* what the series does not cover: exact exp/log sums, one workgroup per variant; \
 			   then the exact dense g_pos / g_neg pass */                                    \
 			/* a packed row in LDS when it fits; short rows: 128 threads per variant, 4 workgroups per CU */ \
@@ -688,22 +692,28 @@ static int launch_spa(sgx_handle *h, RowsRef rr, size_t M, double *out8)
 				h->spa5_attr_set[INPUT] = true;                                              \
 			}                                                                                \
 			const int fx5 = (h->force_exact ? 1 : 0) | (h->spa_abl & ~1);                    \
+			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCA, 0, rd);                \
+			for (int rd = 0; rd < nround; rd++) MOMENTS(KK, SPA4_NCB, 1, rd);                \
+			/* (genotype blocks carry the carrier lists of the rare variants, rr.cptr: the kernels walk those \
+			   instead of scanning the row; spa_abl & 512 makes them scan, as for row-major input) */ \
+			const int only5 = (INPUT == IN_2BIT && rr.cptr != nullptr && (h->spa_abl & 512)) ? 2 : 0; \
+			const size_t ws5 = spa5_wg_bytes(md.N);                                          \
 			if (small5) {                                                                    \
 				/* (2-bit rows only: the constant keeps the other inputs' 128-thread forms uninstantiated) */ \
 				constexpr int IN5 = INPUT == IN_2BIT ? INPUT : IN_2BIT;                      \
 				hipLaunchKernelGGL((spa5_kernel<KK, IN5, 0, 128>), dim3((unsigned)h->nwg5), dim3(128), \
 					l5, st, rr, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
-					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5, only5, ws5, 3); \
 				hipLaunchKernelGGL((spa5_kernel<KK, IN5, 1, 128>), dim3((unsigned)h->nwg5), dim3(128), \
 					l5, st, rr, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
-					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5, only5, ws5, 4); \
 			} else {                                                                         \
 				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 0, 512>), dim3((unsigned)h->n_cu), dim3(512), \
 					l5, st, rr, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
-					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5, only5, ws5, 3); \
 				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 1, 512>), dim3((unsigned)h->n_cu), dim3(512), \
 					l5, st, rr, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
-					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5);            \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5, only5, ws5, 4); \
 			}                                                                                \
 			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rr,    \
 				md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
@@ -729,9 +739,9 @@ static int launch_scan(sgx_handle *h, const void *rows, size_t row_bytes, size_t
 	const DevModel &md = h->md;
 	constexpr int SB = 256;
 	hipStream_t st = h->stream;
-	const RowsRef rr{reinterpret_cast<const uint8_t *>(rows), row_bytes, 0};
+	const RowsRef rr{reinterpret_cast<const uint8_t *>(rows), row_bytes, 0, nullptr, nullptr, nullptr};
 	HIPCHK(hipMemsetAsync(h->counters, 0, 24 * sizeof(int), st));
-	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 4 * sizeof(int), st));
+	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 8 * sizeof(int), st));
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	{
 	const dim3 grid((unsigned)M);
@@ -812,6 +822,7 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 			t->dF = h->dF; t->dX = h->dX; t->dy = h->dy; t->dmu = h->dmu; t->dmu2 = h->dmu2; t->dXM = h->dXM; t->dFl = h->dFl; t->dQ = h->dQ;
 			t->shares_model = true; t->owner = h;
 			t->force_dense = h->force_dense; t->force_v1 = h->force_v1; t->force_exact = h->force_exact;
+			t->spa_abl = h->spa_abl;
 			rc = set_dev(t);
 			if (!rc) rc = alloc_workspace(t);
 			if (rc) { sgx_free(t); return rc; }
@@ -904,6 +915,7 @@ extern "C" void sgx_block_free(sgx_block *b)
 	(void)hipSetDevice(b->device);
 	(void)hipFree(b->tiles); (void)hipFree(b->cnt); (void)hipFree(b->ptr); (void)hipFree(b->idx);
 	(void)hipFree(b->n3); (void)hipFree(b->ovf); (void)hipFree(b->piece);
+	(void)hipFree(b->nzv); (void)hipFree(b->n2v); (void)hipFree(b->cptr); (void)hipFree(b->cidx); (void)hipFree(b->corient);
 	if (b->ready) (void)hipEventDestroy(b->ready);
 	delete b;
 }
@@ -922,8 +934,18 @@ extern "C" int sgx_block_create(int32_t n_samp, size_t max_variants, int device,
 	// the list holds up to max(64, N / 128) missing genotypes per variant on average (0.8 % at large N);
 	// variants beyond a full list, or with more than 16 times that, take the FP64 kernel
 	b->idx_cap = std::min<size_t>(max_variants * std::max<size_t>(64, (size_t)n_samp / 128), 0xF0000000u);
+	// carrier lists: 1536 entries per variant on average (a log-uniform MAF spectrum from 5e-4 lists ~40 % of the
+	// variants at N = 430 000 with ~3 000 carriers each); SAIGEHIP_CLIST_CAP overrides the average (tests)
+	size_t cavg = 1536;
+	if (const char *e5 = getenv("SAIGEHIP_CLIST_CAP")) cavg = (size_t)std::max(0ll, atoll(e5));
+	b->cidx_cap = std::min<size_t>(max_variants * std::min<size_t>(cavg, (size_t)n_samp), 0xF0000000u);
 	hipError_t e = hipSetDevice(device);
 	if (e == hipSuccess) e = hipMalloc((void **)&b->tiles, s3_block_bytes(max_variants, b->ntile));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->nzv, max_variants * sizeof(int));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->n2v, max_variants * sizeof(int));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->cptr, (max_variants + 1) * sizeof(unsigned));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->cidx, std::max<size_t>(b->cidx_cap, 1) * sizeof(unsigned));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->corient, max_variants);
 	if (e == hipSuccess) e = hipMalloc((void **)&b->cnt, (size_t)S3_NR * max_variants * sizeof(int));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->ptr, ((size_t)S3_NR * max_variants + 1) * sizeof(unsigned));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->idx, b->idx_cap * sizeof(unsigned));
@@ -942,7 +964,7 @@ static int block_put_rows(sgx_block *b, const uint8_t *rows_dev, size_t bpv, siz
 {
 	const int nfrag = (int)((m + 15) / 16);
 	hipLaunchKernelGGL(s3_ingest_tile_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, rows_dev, bpv, b->N, (int)m, b->ntile,
-		b->tiles + (v_first / 16) * (size_t)b->ntile * 1024, b->cnt + v_first, b->cap);
+		b->tiles + (v_first / 16) * (size_t)b->ntile * 1024, b->cnt + v_first, b->cap, b->nzv + v_first, b->n2v + v_first);
 	HIPCHK(hipGetLastError());
 	return SGX_OK;
 }
@@ -957,8 +979,10 @@ static int block_finish(sgx_block *b, size_t M, hipStream_t st)
 	hipLaunchKernelGGL(s3_ingest_piece_kernel, dim3((unsigned)npiece), dim3(256), 0, st, (int)M, b->cap, b->cnt, b->ovf, b->piece);
 	hipLaunchKernelGGL(s3_ingest_piece_scan_kernel, dim3(1), dim3(1024), 0, st, npiece, b->piece);
 	hipLaunchKernelGGL(s3_ingest_ptr_kernel, dim3((unsigned)npiece), dim3(256), 0, st, (int)M, b->cap, b->cnt, b->ovf, b->piece, b->ptr);
+	hipLaunchKernelGGL(s3_ingest_clist_kernel, dim3(1), dim3(1024), 0, st, (int)M, b->N, SPA5_NNZ, (unsigned)b->cidx_cap, b->nzv, b->n2v, b->n3, b->cptr, b->corient);
 	const int nfrag = (int)((M + 15) / 16);
-	hipLaunchKernelGGL(s3_ingest_fill_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, b->tiles, (int)M, b->ntile, b->ovf, b->ptr, b->idx);
+	hipLaunchKernelGGL(s3_ingest_fill_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, b->tiles, b->N, (int)M, b->ntile, b->ovf, b->ptr, b->idx,
+		b->corient, b->cptr, b->cidx);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(b->ready, st));
 	b->M = M;
@@ -1023,7 +1047,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	int NCW = 0, NAFW = 0;
 	HIPCHK(hipStreamWaitEvent(st, b->ready, 0));
 	HIPCHK(hipMemsetAsync(h->counters, 0, 24 * sizeof(int), st));
-	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 4 * sizeof(int), st));
+	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 8 * sizeof(int), st));
 	HIPCHK(hipEventRecord(h->ev[0], st));
 	int rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)(S3_NR + 1) * M * md.P * 2);      // per-range partials, then the totals
 	if (rc) return rc;
@@ -1081,7 +1105,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	hipLaunchKernelGGL((score3_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, md, ep, h->mf_acc, \
 		h->s3_t3 + (size_t)S3_NR * M * md.P * 2, b->n3, b->ovf, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid); \
 	hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, 256>), dim3((unsigned)std::min<size_t>(M, 4 * (size_t)h->n_cu)), dim3(256), 0, st, \
-		RowsRef{b->tiles, 0, b->ntile}, (int)M, md, h->recs, h->counters, out8, valid, (const int *)h->s3_ovf, 23, btop, h->fb_spa2, h->fb_x2); \
+		RowsRef{b->tiles, 0, b->ntile, b->cptr, b->cidx, b->corient}, (int)M, md, h->recs, h->counters, out8, valid, (const int *)h->s3_ovf, 23, btop, h->fb_spa2, h->fb_x2); \
 	break;
 	FOR_EACH_K(ECASE)
 #undef ECASE
@@ -1090,7 +1114,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[1], st));
 	h->stats.score_launches = 6;
-	rc = launch_spa<IN_2BIT>(h, RowsRef{b->tiles, 0, b->ntile}, M, out8);
+	rc = launch_spa<IN_2BIT>(h, RowsRef{b->tiles, 0, b->ntile, b->cptr, b->cidx, b->corient}, M, out8);
 	if (rc) return rc;
 	HIPCHK(hipEventRecord(h->ev[2], st));
 	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 24 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1135,7 +1159,7 @@ extern "C" int sgx_scan_block(sgx_handle *h, const sgx_block *b, double *out8_de
 		// FP64 kernels on the tiled rows (test hook; models outside the fixed-point form's range)
 		hipStream_t st = lane->stream;
 		HIPCHK(hipMemsetAsync(lane->counters, 0, 24 * sizeof(int), st));
-		if (lane->cur5) HIPCHK(hipMemsetAsync(lane->cur5, 0, 4 * sizeof(int), st));
+		if (lane->cur5) HIPCHK(hipMemsetAsync(lane->cur5, 0, 8 * sizeof(int), st));
 		HIPCHK(hipEventRecord(lane->ev[0], st));
 		const RowsRef rr{b->tiles, 0, b->ntile};
 		switch (lane->md.K) {

@@ -332,6 +332,32 @@ def test_fallback_paths_give_identical_rows(option, value, counter):
     np.testing.assert_allclose(out[v][:, 3:7], base[v][:, 3:7], rtol=1e-11)
 
 
+def test_block_carrier_lists_equal_row_scans(monkeypatch):
+    """Genotype blocks list the carriers of the rare variants (both orientations: 10 % of the synthetic variants
+    have the alt allele as the major one); the per-variant SPA kernels walk those lists.  Same rows when the
+    lists are ignored ("spa_abl" 512: every variant scans its row), when the block's list is too small for all
+    of them (SAIGEHIP_CLIST_CAP: the later variants go unlisted), and through the exact sweeps."""
+    sm, packed = _synthetic_case(3001, 1200, "binary", 0.05, seed=29)
+    ref, ref_valid = _oracle(sm).scan_2bit(packed)
+    v = ref_valid.astype(bool)
+    with _scanner(sm) as sc:
+        base, valid = sc.scan_2bit(packed)
+        assert sc.stats()["n_spa"] > 30
+        assert_table_close(base, valid, ref, ref_valid, what="carrier lists")
+        sc.set_option("spa_abl", 512)
+        rows, _ = sc.scan_2bit(packed)
+        np.testing.assert_allclose(rows[v][:, 3:7], base[v][:, 3:7], rtol=1e-11)
+        sc.set_option("spa_abl", 0)
+        sc.set_option("spa_exact", 1)
+        exact, valid = sc.scan_2bit(packed)
+        assert_table_close(exact, valid, ref, ref_valid, what="carrier lists, exact sweeps")
+    monkeypatch.setenv("SAIGEHIP_CLIST_CAP", "40")     # 48 000 entries for 1 200 variants with ~300 carriers each
+    with _scanner(sm) as sc:
+        part, valid = sc.scan_2bit(packed)
+    assert_table_close(part, valid, ref, ref_valid, what="carrier lists, full list")
+    np.testing.assert_allclose(part[v][:, 3:7], base[v][:, 3:7], rtol=1e-11)
+
+
 def test_two_lanes_give_identical_tables():
     """"lanes" = 2: successive device-resident scans alternate between two streams with their own
     workspace; every block's table must equal the single-lane one, and the totals must add up."""

@@ -14,7 +14,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof2 -- python3 $R
 cd $ROOT
 find $OUT/prof2 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_two_lanes.csv \;
 find $OUT/prof1 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_one_lane.csv \;
+find $OUT/prof1 -name "*kernel_trace.csv" -exec cp {} $OUT/kernel_trace_one_lane.csv \;
+find $OUT/prof2 -name "*kernel_trace.csv" -exec cp {} $OUT/kernel_trace_two_lanes.csv \;
 rm -rf $OUT/prof1 $OUT/prof2
 python3 tools/bench_brief.py $OUT/bench.json || true
 echo "--- one lane"; python3 profiles/show_stats.py $OUT/kernel_stats_one_lane.csv | head -24
+echo "--- one lane, one step"; python3 profiles/show_timeline.py $OUT/kernel_trace_one_lane.csv || true
 echo "--- two lanes"; python3 profiles/show_stats.py $OUT/kernel_stats_two_lanes.csv | head -24
