@@ -107,6 +107,8 @@ typedef struct sgx_stats {
 	float ms_total;        /* first launch .. last launch complete, ms        */
 	uint32_t score_launches;
 	uint32_t spa_launches;
+	float ms_kernel;       /* HIP-event time of the genotype-streaming kernel alone (score3_kernel), ms;
+	                          0 where the scan took the FP64 kernels                                      */
 } sgx_stats;
 
 /* Library / device ------------------------------------------------------- */
@@ -155,18 +157,23 @@ int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev,
  * (R/assoc_single.r:202-209, seqApply).  Here the unit that is brought into HBM and scanned is a
  * BLOCK of variants: on load the rows are rearranged on the device into tiles of 16 variants x 256
  * samples (one contiguous KiB each: what a wavefront of the score kernel reads with one instruction)
- * and the positions of the missing genotypes are listed per variant.  A block depends on the number
- * of samples only, so one loaded block can be scanned with any number of models (phenotypes).
+ * and the positions of the missing genotypes are listed per variant, as are the carriers (sample and
+ * code, ascending) of every variant with at most 8 192 of them in the orientation the scan will use
+ * (non-zero codes, or the codes other than 2 where the alt allele is the major one) -- the sparse
+ * form of a rare variant that f64_nonzero_index (src/saige_main.cpp) builds per variant in the
+ * reference, here built once per block.  A block depends on the number of samples only, so one loaded
+ * block can be scanned with any number of models (phenotypes).
  * sgx_scan_2bit / sgx_scan_2bit_dev are this load followed by sgx_scan_block on a scratch block.
  *   sgx_block_create    device storage for up to max_variants rows of n_samp samples
- *   sgx_block_bytes     what that takes (rows + lists: about 1.13 x the packed rows at large N)
+ *   sgx_block_bytes     what that takes (rows + lists: about 1.19 x the packed rows at large N)
  *   sgx_block_load_dev  rows already in this GPU's memory (bytes_per_variant a multiple of 16,
  *                       >= sgx_row_stride(n_samp), 16-byte aligned); asynchronous on the handle's stream
  *   sgx_block_load      rows in host memory (>= ceil(n_samp / 4) bytes each), through the pinned pipeline
  *   sgx_scan_block      the scan; asynchronous like sgx_scan_2bit_dev (same lanes, stats, sgx_sync)
  * Variants with more missing genotypes than the block's lists hold (a list entry per missing
  * genotype, room for 0.8 % of the block at large N) are scanned by the FP64 kernels instead: same
- * results, slower. */
+ * results, slower.  Rare variants beyond a full carrier list (1 536 entries per variant of the block
+ * on average) have their rows scanned by the SPA kernels, as row-major input has: same results. */
 typedef struct sgx_block sgx_block;
 size_t sgx_block_bytes(int32_t n_samp, size_t max_variants);
 int  sgx_block_create(int32_t n_samp, size_t max_variants, int device, sgx_block **out);

@@ -44,7 +44,7 @@ class SgxStats(C.Structure):
         ("n_variants", C.c_uint64), ("n_valid", C.c_uint64), ("n_spa", C.c_uint64),
         ("n_spa_dense", C.c_uint64), ("n_spa_slow", C.c_uint64),
         ("ms_score", C.c_float), ("ms_spa", C.c_float), ("ms_total", C.c_float),
-        ("score_launches", C.c_uint32), ("spa_launches", C.c_uint32),
+        ("score_launches", C.c_uint32), ("spa_launches", C.c_uint32), ("ms_kernel", C.c_float),
     ]
 
     def as_dict(self):

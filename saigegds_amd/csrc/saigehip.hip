@@ -153,15 +153,19 @@ struct sgx_handle {
 	double *ds_part = nullptr; size_t ds_part_cap = 0;       // dosage score kernels: per-split partial sums
 	double *stage_out = nullptr; uint8_t *stage_valid = nullptr; size_t stage_out_cap = 0;
 	hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+	hipEvent_t evk[2] = {nullptr, nullptr};    // around the contraction kernel alone (stats.ms_kernel)
+	bool evk_set = false;
 	sgx_stats stats{};
 	bool force_v1 = false;            // SAIGEHIP_SCORE_V1=1: gather kernel instead of the MFMA path
 	bool stats_pending = false;
-	// Two lanes ("lanes" option): device-resident scans alternate between this handle and a twin
-	// with its own stream and workspace (the model arrays are shared), so that the SPA stage of
-	// one block of variants runs while the score stage of the next one streams the genotypes.
+	// Lanes ("lanes" option, 1..SGX_MAX_LANES): device-resident scans go round-robin over this handle and
+	// its twins, each with its own stream and workspace (the model arrays are shared), so that the SPA stage
+	// of one block of variants runs while the score stage of the next one streams the genotypes, and -- where
+	// the blocks are small (N = 50 000) -- the many short kernels of a step find others to run beside.
 	// Score stages never overlap each other (the later one waits for the earlier one's event).
-	sgx_handle *twin = nullptr;       // owned by the primary handle
-	sgx_handle *owner = nullptr;      // set in the twin
+	sgx_handle *twins[3] = {nullptr, nullptr, nullptr};   // owned by the primary handle
+	int n_lanes = 1;
+	sgx_handle *owner = nullptr;      // set in a twin
 	bool shares_model = false;        // twin: dF .. dFl belong to the owner
 	int next_lane = 0;                // primary: which lane takes the next _dev call
 	sgx_handle *last_issued = nullptr;// primary: lane of the most recent call
@@ -201,7 +205,7 @@ extern "C" int sgx_set_thresholds(sgx_handle *h, double maf, double mac, double 
 	h->md.thr_mac = thr_or(mac, -1);
 	h->md.thr_missing = thr_or(missing, 1);
 	h->md.thr_spa = thr_or(spa_pval, 0.05);
-	if (h->twin) return sgx_set_thresholds(h->twin, maf, mac, missing, spa_pval);
+	for (sgx_handle *t : h->twins) if (t) { int rc = sgx_set_thresholds(t, maf, mac, missing, spa_pval); if (rc) return rc; }
 	return SGX_OK;
 }
 
@@ -292,6 +296,7 @@ static int alloc_workspace(sgx_handle *h)
 	HIPCHK(hipMalloc((void **)&h->counters, 24 * sizeof(int)));
 	HIPCHK(hipHostMalloc((void **)&h->h_counters, 24 * sizeof(int), hipHostMallocDefault));
 	for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&h->ev[i]));
+	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreate(&h->evk[i]));
 	// SPA scratch: one (adj, mu) list of N entries per resident workgroup
 	hipDeviceProp_t prop;
 	HIPCHK(hipGetDeviceProperties(&prop, h->device));
@@ -547,7 +552,7 @@ extern "C" void sgx_free(sgx_handle *h)
 	if (!h) return;
 	(void)hipSetDevice(h->device);
 	if (h->stream) (void)hipStreamSynchronize(h->stream);
-	if (h->twin) { sgx_free(h->twin); h->twin = nullptr; }
+	for (sgx_handle *&t : h->twins) if (t) { sgx_free(t); t = nullptr; }
 	if (!h->shares_model) {
 		(void)hipFree(h->dF); (void)hipFree(h->dX); (void)hipFree(h->dy);
 		(void)hipFree(h->dmu); (void)hipFree(h->dmu2); (void)hipFree(h->dXM); (void)hipFree(h->dFl); (void)hipFree(h->dQ);
@@ -569,6 +574,7 @@ extern "C" void sgx_free(sgx_handle *h)
 	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid); (void)hipFree(h->stage_pk); (void)hipFree(h->ds_part);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
 	for (int i = 0; i < 3; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
+	for (int i = 0; i < 2; i++) if (h->evk[i]) (void)hipEventDestroy(h->evk[i]);
 	if (h->s3_side) { (void)hipStreamSynchronize(h->s3_side); (void)hipStreamDestroy(h->s3_side); }
 	if (h->s3_fork) (void)hipEventDestroy(h->s3_fork);
 	if (h->s3_join) (void)hipEventDestroy(h->s3_join);
@@ -810,12 +816,13 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 	else if (n == "pipe_mb") { if (value < 0 || value > 65536) return fail(SGX_EINVAL, "pipe_mb out of range"); h->pipe_bytes = (size_t)value << 20; return SGX_OK; }
 	else if (n == "spa_abl") h->spa_abl = (int)value;
 	else if (n == "lanes") {
-		if (value != 1 && value != 2) return fail(SGX_EINVAL, "lanes must be 1 or 2");
+		if (value < 1 || value > 4) return fail(SGX_EINVAL, "lanes must be 1..4");
 		if (h->owner) return fail(SGX_EINVAL, "lanes: not on a twin");
 		int rc = sgx_sync(h);
 		if (rc) return rc;
-		if (value == 1 && h->twin) { sgx_free(h->twin); h->twin = nullptr; h->next_lane = 0; h->last_issued = nullptr; }
-		if (value == 2 && !h->twin) {
+		for (int i = (int)value - 1; i < 3; i++) if (h->twins[i]) { sgx_free(h->twins[i]); h->twins[i] = nullptr; }
+		for (int i = 0; i < (int)value - 1; i++) {
+			if (h->twins[i]) continue;
 			sgx_handle *t = new sgx_handle();
 			t->device = h->device; t->md = h->md; t->mf_ok = h->mf_ok; t->mfe = h->mfe;
 			for (int g = 0; g < MF_MAXG; g++) { t->mf[g] = h->mf[g]; t->mf_nbfv[g] = h->mf_nbfv[g]; }
@@ -826,12 +833,13 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 			rc = set_dev(t);
 			if (!rc) rc = alloc_workspace(t);
 			if (rc) { sgx_free(t); return rc; }
-			h->twin = t;
+			h->twins[i] = t;
 		}
+		h->n_lanes = (int)value; h->next_lane = 0; h->last_issued = nullptr;
 		return SGX_OK;
 	}
 	else return fail(SGX_EINVAL, "sgx_set_option: unknown option '%s'", name);
-	if (h->twin) return sgx_set_option(h->twin, name, value);
+	for (sgx_handle *t : h->twins) if (t) { int rc = sgx_set_option(t, name, value); if (rc) return rc; }
 	return SGX_OK;
 }
 
@@ -858,12 +866,15 @@ static int sync_lane(sgx_handle *h)
 		(void)hipEventElapsedTime(&b, h->ev[1], h->ev[2]);
 		(void)hipEventElapsedTime(&c, h->ev[0], h->ev[2]);
 		h->stats.ms_score = a; h->stats.ms_spa = b; h->stats.ms_total = c;
+		float k = 0;
+		if (h->evk_set) (void)hipEventElapsedTime(&k, h->evk[0], h->evk[1]);
+		h->stats.ms_kernel = k; h->evk_set = false;
 		h->stats_pending = false;
 		sgx_handle *p = h->owner ? h->owner : h;
 		const sgx_stats &x = h->stats;
 		p->total.n_variants += x.n_variants; p->total.n_valid += x.n_valid; p->total.n_spa += x.n_spa;
 		p->total.n_spa_dense += x.n_spa_dense; p->total.n_spa_slow += x.n_spa_slow;
-		p->total.ms_score += x.ms_score; p->total.ms_spa += x.ms_spa; p->total.ms_total += x.ms_total;
+		p->total.ms_score += x.ms_score; p->total.ms_spa += x.ms_spa; p->total.ms_total += x.ms_total; p->total.ms_kernel += x.ms_kernel;
 		p->total.score_launches += x.score_launches; p->total.spa_launches += x.spa_launches;
 		p->total_calls++;
 	}
@@ -874,7 +885,7 @@ extern "C" int sgx_sync(sgx_handle *h)
 {
 	if (!h) return fail(SGX_EINVAL, "sgx_sync: NULL handle");
 	int rc = sync_lane(h);
-	if (!rc && h->twin) rc = sync_lane(h->twin);
+	for (sgx_handle *t : h->twins) if (!rc && t) rc = sync_lane(t);
 	return rc;
 }
 
@@ -906,7 +917,8 @@ extern "C" size_t sgx_block_bytes(int32_t n_samp, size_t max_variants)
 	if (n_samp <= 0 || max_variants == 0) return 0;
 	const int ntile = 2 * ((n_samp + 511) / 512);
 	const size_t lim = std::max<size_t>(64, (size_t)n_samp / 128);
-	return s3_block_bytes(max_variants, ntile) + max_variants * lim * 4 + max_variants * (S3_NR * 8 + 5) + 4;
+	const size_t clist = max_variants * std::min<size_t>(1536, (size_t)n_samp) * 4;       // carrier lists (sgx_block_create)
+	return s3_block_bytes(max_variants, ntile) + max_variants * lim * 4 + clist + max_variants * (S3_NR * 8 + 5 + 13) + 8;
 }
 
 extern "C" void sgx_block_free(sgx_block *b)
@@ -1085,8 +1097,11 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 			HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
 			h->s3_attr[NBF_] = true;                                                                      \
 		}                                                                                                 \
+		HIPCHK(hipEventRecord(h->evk[0], st));                                                            \
 		hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (NC_ + NLA_ + NLB_)), lds, st,            \
 			(const uint8_t *)b->tiles, (const uint8_t *)h->dFl, pl, h->s3_slabs, (unsigned long long *)nullptr); \
+		HIPCHK(hipEventRecord(h->evk[1], st));                                                            \
+		h->evk_set = true;                                                                                \
 	} break;
 		S3_FOR_EACH_NBF(S3CASE)
 #undef S3CASE
@@ -1127,10 +1142,10 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 static int next_lane(sgx_handle *h, size_t M, sgx_handle **lane_out)
 {
 	sgx_handle *lane = h, *other = nullptr;
-	if (h->twin) {
-		lane = h->next_lane ? h->twin : h;
-		other = h->next_lane ? h : h->twin;
-		h->next_lane ^= 1;
+	if (h->n_lanes > 1) {
+		lane = h->next_lane ? h->twins[h->next_lane - 1] : h;
+		other = h->last_issued;                    // the lane of the previous call
+		h->next_lane = (h->next_lane + 1) % h->n_lanes;
 	}
 	int rc = sync_lane(lane);            // the lane's previous call is done: keep its stats (events are reused)
 	if (rc) return rc;
@@ -1138,7 +1153,7 @@ static int next_lane(sgx_handle *h, size_t M, sgx_handle **lane_out)
 	rc = ensure_recs(lane, M);
 	if (rc) return rc;
 	// score stages do not overlap: this one starts after the other lane's has ended
-	if (other && other->stats_pending) HIPCHK(hipStreamWaitEvent(lane->stream, other->ev[1], 0));
+	if (other && other != lane && other->stats_pending) HIPCHK(hipStreamWaitEvent(lane->stream, other->ev[1], 0));
 	*lane_out = lane;
 	return SGX_OK;
 }
