@@ -229,10 +229,11 @@ int sgx_geno_stats_2bit(const uint8_t *packed, size_t bytes_per_variant, int32_t
 
 /* Tuning / test hooks: "spa_exact" (every flagged variant through the exact exp/log SPA kernel instead
  * of the cumulant series), "force_dense" (exact g_pos/g_neg pass for every SPA variant), "score_v1"
- * (FP64 gather score kernel instead of the MFMA path), "lanes" (1 or 2: with 2, successive
- * sgx_scan_2bit_dev calls alternate between two streams with their own workspace, so the SPA stage of
- * one block runs under the score stage of the next; call sgx_sync() before reading any output),
- * "pipe_mb" (MiB of input rows per chunk of a host-buffer scan; 0 = default 512).
+ * (FP64 gather score kernel instead of the MFMA path), "lanes" (1..4: successive sgx_scan_block /
+ * sgx_scan_2bit_dev calls go round-robin over that many streams with their own workspace, so the SPA
+ * stage of one block runs under the score stage of the next; call sgx_sync() before reading any
+ * output), "pipe_mb" (MiB of input rows per chunk of a host-buffer scan; 0 = default 512), "spa_abl"
+ * (diagnostic bits; 512: the SPA kernels scan the rows of a block instead of walking its carrier lists).
  * Results never depend on them beyond rounding (1e-12). */
 int sgx_set_option(sgx_handle *h, const char *name, long long value);
 

@@ -475,33 +475,38 @@ s3_ingest_piece_scan_kernel(int npiece, unsigned long long *__restrict__ piece)
 // the scan will flip it (make_head: AF > 0.5, from the same integer counts) -- gets its carriers listed in
 // ascending sample order at cidx[cptr[v] .. cptr[v + 1]) as sample | code << 30; corient[v] = 1 / 2 says which
 // orientation the list is for, 0 = no list (too many carriers, or the block's list is full: the kernels then
-// scan the variant's row as they do for row-major input).  One workgroup: the offsets in variant order.
+// scan the variant's row as they do for row-major input).
+__global__ void __launch_bounds__(256)
+s3_ingest_clist_count_kernel(int M, int N, int lim, int *__restrict__ nzv /* in: non-zero codes; out: listed carriers */,
+	const int *__restrict__ n2v, const int *__restrict__ n3, uint8_t *__restrict__ corient)
+{
+	const int v = blockIdx.x * 256 + threadIdx.x;
+	if (v >= M) return;
+	const int nz = nzv[v], n2 = n2v[v], m3 = n3[v];
+	const long long AC = (long long)(nz - n2 - m3) + 2ll * n2;
+	const bool minus = (double)AC / (2.0 * (double)(N - m3)) > 0.5;      // make_head (dev_common.h)
+	const int nnz = minus ? N - n2 : nz;
+	const int orient = (N - m3 > 0 && nnz <= lim) ? (minus ? 2 : 1) : 0;
+	corient[v] = (uint8_t)orient;
+	nzv[v] = orient ? nnz : 0;
+}
+
+// one workgroup: the offsets in variant order; a variant that no longer fits the block's list goes unlisted
+// (and, the sum only growing, so do the later ones that do not fit; their offsets stay valid, empty ranges)
 __global__ void __launch_bounds__(1024)
-s3_ingest_clist_kernel(int M, int N, int lim, unsigned cidx_cap, const int *__restrict__ nzv, const int *__restrict__ n2v,
-	const int *__restrict__ n3, unsigned *__restrict__ cptr, uint8_t *__restrict__ corient)
+s3_ingest_clist_kernel(int M, unsigned cidx_cap, const int *__restrict__ cn, unsigned *__restrict__ cptr, uint8_t *__restrict__ corient)
 {
 	__shared__ unsigned long long sh[1024];
 	const int tid = threadIdx.x, per = (M + 1023) / 1024, v0 = tid * per, v1 = min(M, v0 + per);
-	auto listed = [&](int v, int &orient) -> int {
-		const int nz = nzv[v], n2 = n2v[v], m3 = n3[v];
-		const long long AC = (long long)(nz - n2 - m3) + 2ll * n2;
-		const bool minus = (double)AC / (2.0 * (double)(N - m3)) > 0.5;      // make_head (dev_common.h)
-		const int nnz = minus ? N - n2 : nz;
-		orient = (N - m3 > 0 && nnz <= lim) ? (minus ? 2 : 1) : 0;
-		return orient ? nnz : 0;
-	};
 	unsigned long long mine = 0;
-	for (int v = v0; v < v1; v++) { int o; mine += (unsigned long long)listed(v, o); }
+	for (int v = v0; v < v1; v++) mine += (unsigned long long)cn[v];
 	unsigned long long base = s3_block_excl(mine, sh);
 	for (int v = v0; v < v1; v++) {
-		int o;
-		const int n = listed(v, o);
+		const int n = cn[v];
 		const bool fits = base + (unsigned long long)n <= (unsigned long long)cidx_cap;
-		// (a full list: this variant and, the sum only growing, the later ones that do not fit go unlisted;
-		// their offsets stay valid, empty ranges)
 		cptr[v] = (unsigned)min(base, (unsigned long long)cidx_cap);
-		corient[v] = fits ? (uint8_t)o : (uint8_t)0;
-		if (fits) base += (unsigned long long)n;
+		if (!fits) corient[v] = 0;
+		else base += (unsigned long long)n;
 	}
 	if (tid == 1023) cptr[M] = (unsigned)min(base, (unsigned long long)cidx_cap);
 }
@@ -548,6 +553,7 @@ s3_ingest_fill_kernel(const uint8_t *__restrict__ tiles, int N, int M, int ntile
 	constexpr int UN = 4;
 	int rg = -1, tend = 0;
 	unsigned off = 0, coff = orient ? cptr[v] : 0u;
+	const bool any_listed = __ballot(orient != 0) != 0;
 	for (int t0 = 0; t0 < ntile; t0 += UN) {
 		uint4 w[UN];
 #pragma unroll
@@ -561,18 +567,26 @@ s3_ingest_fill_kernel(const uint8_t *__restrict__ tiles, int N, int M, int ntile
 			if (t >= ntile) break;
 			while (t >= tend) { rg++; tend = s3_range_t0(rg + 1, ntile); off = live ? ptr[(size_t)rg * M + v] : 0u; }
 			const uint32_t d[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
-			uint32_t m[4], z[4];
+			uint32_t m[4], z[4] = {0u, 0u, 0u, 0u};
 			int c = 0, cc = 0;
 			const int s0 = t * 256 + kg * 64;
 #pragma unroll
 			for (int u = 0; u < 4; u++) {
 				m[u] = live ? (d[u] & (d[u] >> 1) & 0x55555555u) : 0u;
 				c += __popc(m[u]);
-				const int keep = N - s0 - 16 * u;     // (the padding samples hold code 0: carriers of a flipped variant otherwise)
-				const uint32_t km = (keep >= 16) ? 0xFFFFFFFFu : ((keep <= 0) ? 0u : ((1u << (2 * keep)) - 1u));
-				const uint32_t x = (d[u] ^ zx) & km;
-				z[u] = orient ? ((x | (x >> 1)) & 0x55555555u) : 0u;
-				cc += __popc(z[u]);
+			}
+			if (any_listed) {
+				const bool full = (t + 1) * 256 <= N;     // (the padding samples hold code 0: carriers of a flipped variant otherwise)
+#pragma unroll
+				for (int u = 0; u < 4; u++) {
+					uint32_t x = d[u] ^ zx;
+					if (!full) {
+						const int keep = N - s0 - 16 * u;
+						x &= (keep >= 16) ? 0xFFFFFFFFu : ((keep <= 0) ? 0u : ((1u << (2 * keep)) - 1u));
+					}
+					z[u] = orient ? ((x | (x >> 1)) & 0x55555555u) : 0u;
+					cc += __popc(z[u]);
+				}
 			}
 			if (!__ballot((c | cc) != 0)) continue;
 			// exclusive prefix over the four kg lanes of the variant

@@ -991,7 +991,8 @@ static int block_finish(sgx_block *b, size_t M, hipStream_t st)
 	hipLaunchKernelGGL(s3_ingest_piece_kernel, dim3((unsigned)npiece), dim3(256), 0, st, (int)M, b->cap, b->cnt, b->ovf, b->piece);
 	hipLaunchKernelGGL(s3_ingest_piece_scan_kernel, dim3(1), dim3(1024), 0, st, npiece, b->piece);
 	hipLaunchKernelGGL(s3_ingest_ptr_kernel, dim3((unsigned)npiece), dim3(256), 0, st, (int)M, b->cap, b->cnt, b->ovf, b->piece, b->ptr);
-	hipLaunchKernelGGL(s3_ingest_clist_kernel, dim3(1), dim3(1024), 0, st, (int)M, b->N, SPA5_NNZ, (unsigned)b->cidx_cap, b->nzv, b->n2v, b->n3, b->cptr, b->corient);
+	hipLaunchKernelGGL(s3_ingest_clist_count_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, b->N, SPA5_NNZ, b->nzv, b->n2v, b->n3, b->corient);
+	hipLaunchKernelGGL(s3_ingest_clist_kernel, dim3(1), dim3(1024), 0, st, (int)M, (unsigned)b->cidx_cap, b->nzv, b->cptr, b->corient);
 	const int nfrag = (int)((M + 15) / 16);
 	hipLaunchKernelGGL(s3_ingest_fill_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, b->tiles, b->N, (int)M, b->ntile, b->ovf, b->ptr, b->idx,
 		b->corient, b->cptr, b->cidx);

@@ -16,6 +16,7 @@ echo "configs done"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof2 -- python3 $ROOT/bench.py --steps 20 --warmup 2 --cpu-seconds 0 --host-variants 0 --file-variants 0 --secondary 0 > $OUT/bench_under_rocprof.json 2> $OUT/prof2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof1 -- python3 $ROOT/bench.py --steps 20 --warmup 2 --cpu-seconds 0 --host-variants 0 --file-variants 0 --secondary 0 --lanes 1 > $OUT/bench_under_rocprof_one_lane.json 2> $OUT/prof1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof13 -- python3 $ROOT/bench.py --k 13 --steps 10 --warmup 2 --cpu-seconds 0 --host-variants 0 --file-variants 0 --secondary 0 --lanes 1 > $OUT/bench_k13_under_rocprof_one_lane.json 2> $OUT/prof13.err
 echo "kernel stats done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc_rd -- python3 $ROOT/bench.py --steps 4 --warmup 1 --cpu-seconds 0 --host-variants 0 --file-variants 0 --secondary 0 --lanes 1 > $OUT/pmc_rd.json 2> $OUT/pmc_rd.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_wr -- python3 $ROOT/bench.py --steps 4 --warmup 1 --cpu-seconds 0 --host-variants 0 --file-variants 0 --secondary 0 --lanes 1 > $OUT/pmc_wr.json 2> $OUT/pmc_wr.err
@@ -27,5 +28,8 @@ python3 profiles/show_pmc.py $OUT/pmc_rd $OUT/pmc_wr > $OUT/pmc_tcc.txt
 python3 profiles/show_pmc.py $OUT/pmc_sq > $OUT/pmc_sq.txt
 find $OUT/prof2 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_two_lanes.csv \;
 find $OUT/prof1 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_one_lane.csv \;
-rm -rf $OUT/prof1 $OUT/prof2 $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_sq
+find $OUT/prof13 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_k13_one_lane.csv \;
+find $OUT/prof1 -name "*kernel_trace.csv" -exec python3 profiles/show_timeline.py {} \; > $OUT/timeline_one_lane.txt || true
+find $OUT/prof2 -name "*kernel_trace.csv" -exec python3 profiles/show_timeline.py {} 4 \; > $OUT/timeline_two_lanes.txt || true
+rm -rf $OUT/prof1 $OUT/prof2 $OUT/prof13 $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_sq
 ls -la $OUT
