@@ -279,22 +279,30 @@ spa4_moments(RowsRef rr, DevModel md, int nseg, int tier, int btop, int v0, int 
 			uint32_t lo = nzm(wd0, 0) | (nzm(wd1, 1) << 1), hi = nzm(wd2, 2) | (nzm(wd3, 3) << 1);
 			if (abl & 4) lo = hi = 0;
 			// Software pipeline: the table row and the dosage of a lane's next carrier are read from
-			// LDS before the arithmetic of the current one, into the other of two register sets.
+			// LDS before the arithmetic of the current one, into the other of two register sets.  The reads
+			// are UNCONDITIONAL (a lane without a carrier left reads its first sample's row and uses nothing
+			// of it) and the bit walk is selects only: with the reads inside a branch the compiler cannot count
+			// how many LDS operations are in flight at the use of the OTHER set and waits for all of them,
+			// i.e. for the reads it has just issued (lgkmcnt(2..0) where it now emits lgkmcnt(5..3)).  Worth
+			// nothing measurable at two waves per SIMD (0.99 ms either way: the other wave covers the wait),
+			// kept because the loop is 20 instructions shorter.
 			struct Car { double x[K + 1], G; bool ok; };
+			const uint64_t wlo = ((uint64_t)wd1 << 32) | wd0, whi = ((uint64_t)wd3 << 32) | wd2;
 			auto fetch = [&](Car &cr) {
-				cr.ok = (lo | hi) != 0;
-				if (cr.ok) {
-					const bool inlo = lo != 0;
-					const int b = __ffs(inlo ? lo : hi) - 1;
-					if (inlo) lo &= lo - 1; else hi &= hi - 1;
-					const int dwi = (inlo ? 0 : 2) + (b & 1), sid = b >> 1;
-					const uint32_t wsel = dwi == 0 ? wd0 : dwi == 1 ? wd1 : dwi == 2 ? wd2 : wd3;
-					const uint32_t code = (wsel >> (2 * sid)) & 3u;
-					const double *x = tab + (size_t)((lane * LDW + dwi) * 16 + sid) * KP;
+				const bool inlo = lo != 0;
+				const uint32_t m = inlo ? lo : hi;
+				cr.ok = m != 0;
+				const int b = cr.ok ? __ffs(m) - 1 : 0;
+				const uint32_t m2 = m & (m - 1);
+				lo = inlo ? m2 : lo;
+				hi = inlo ? hi : m2;
+				const int dw = b & 1, sid = b >> 1;                              // dword of the pair, sample in it
+				const uint64_t wsel = inlo ? wlo : whi;
+				const uint32_t code = (uint32_t)(wsel >> (32 * dw + 2 * sid)) & 3u;
+				const double *x = tab + (size_t)((lane * LDW + (inlo ? 0 : 2) + dw) * 16 + sid) * KP;
 #pragma unroll
-					for (int a = 0; a <= K; a++) cr.x[a] = x[a];
-					cr.G = lut[code * SPA4_VPER];
-				}
+				for (int a = 0; a <= K; a++) cr.x[a] = x[a];
+				cr.G = lut[code * SPA4_VPER];
 			};
 			auto work = [&](const Car &cr) {
 				double bb = 0;
@@ -319,13 +327,23 @@ spa4_moments(RowsRef rr, DevModel md, int nseg, int tier, int btop, int v0, int 
 			// idle lane-steps do.)
 			const int ctot = wave_sum_i(__popc(lo) + __popc(hi));
 			const int T = (abl & 256) ? max(0, (ctot - spa4_qcap(K) + WAVE - 1) / WAVE) : (ctot + WAVE - 1) / WAVE;
+			// exactly T fetches, none of them inside a branch of the loop body
 			Car ca, cb;
-			if (T > 0) fetch(ca);
-			for (int it = 0; it < T; it += 2) {
-				if (it + 1 < T) fetch(cb); else cb.ok = false;
-				if (ca.ok) work(ca);
-				if (it + 2 < T) fetch(ca); else ca.ok = false;
-				if (cb.ok) work(cb);
+			ca.ok = cb.ok = false;
+			if (T > 0) {
+				fetch(ca);
+				int it = 1;
+				for (; it + 1 < T; it += 2) {
+					fetch(cb);
+					if (ca.ok) work(ca);
+					fetch(ca);
+					if (cb.ok) work(cb);
+				}
+				if (it < T) {
+					fetch(cb);
+					if (ca.ok) work(ca);
+					if (cb.ok) work(cb);
+				} else if (ca.ok) work(ca);
 			}
 			if (__ballot((lo | hi) != 0)) {
 				const int rem = __popc(lo) + __popc(hi);
@@ -347,21 +365,19 @@ spa4_moments(RowsRef rr, DevModel md, int nseg, int tier, int btop, int v0, int 
 				}
 				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own LDS writes, in order
 				__builtin_amdgcn_wave_barrier();
-				auto fetch_q = [&](Car &cr, int k) {
+				auto fetch_q = [&](Car &cr, int k) {            // unconditional reads, as in fetch (nq > 0 here)
 					cr.ok = k < nq;
-					if (cr.ok) {
-						const uint32_t e = q[k];
-						const double *x = tab + (size_t)(e & 0x3FFFu) * KP;
+					const uint32_t e = q[min(k, nq - 1)];
+					const double *x = tab + (size_t)(e & 0x3FFFu) * KP;
 #pragma unroll
-						for (int a = 0; a <= K; a++) cr.x[a] = x[a];
-						cr.G = lut[(e >> 14) * SPA4_VPER];
-					}
+					for (int a = 0; a <= K; a++) cr.x[a] = x[a];
+					cr.G = lut[(e >> 14) * SPA4_VPER];
 				};
 				fetch_q(ca, lane);
-				for (int k = lane; k < nq; k += 2 * WAVE) {
-					fetch_q(cb, k + WAVE);
+				for (int k0 = 0; k0 < nq; k0 += 2 * WAVE) {          // (wave-uniform bounds)
+					fetch_q(cb, k0 + WAVE + lane);
 					if (ca.ok) work(ca);
-					fetch_q(ca, k + 2 * WAVE);
+					fetch_q(ca, k0 + 2 * WAVE + lane);
 					if (cb.ok) work(cb);
 				}
 				__builtin_amdgcn_wave_barrier();      // queue reads stay before the next variant's writes
