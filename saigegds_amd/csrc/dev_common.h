@@ -226,6 +226,41 @@ __device__ __forceinline__ int wave_sum_i(int v)
 	return v;
 }
 
+// Inclusive prefix sum over the 64 lanes by data-parallel-primitive moves (gfx9 DPP: shifts inside the rows of
+// 16 lanes, then the two row broadcasts) -- six vector instructions and no trip through the LDS crossbar, where
+// the shuffle form pays six dependent ds_bpermute latencies.  Lane 63 holds the total.
+__device__ __forceinline__ int wave_scan_incl_i(int v)
+{
+	v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);   // row_shr:1
+	v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);   // row_shr:2
+	v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);   // row_shr:4
+	v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);   // row_shr:8
+	v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+	v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+	return v;
+}
+// the wave's total of v, wave-uniform (a scalar register)
+__device__ __forceinline__ int wave_total_i(int v) { return __builtin_amdgcn_readlane(wave_scan_incl_i(v), WAVE - 1); }
+// maximum of non-negative doubles over the wave by the same moves; lane 63 holds it (lanes a move does not
+// reach see 0)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROWS, 0xf, false);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROWS, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_max_nonneg_to_last(double v)
+{
+	v = fmax(v, dpp_f64<0x111, 0xf>(v));
+	v = fmax(v, dpp_f64<0x112, 0xf>(v));
+	v = fmax(v, dpp_f64<0x114, 0xf>(v));
+	v = fmax(v, dpp_f64<0x118, 0xf>(v));
+	v = fmax(v, dpp_f64<0x142, 0xa>(v));
+	v = fmax(v, dpp_f64<0x143, 0xc>(v));
+	return v;
+}
+
 // Sum NV doubles per thread over the workgroup; every thread gets the totals.
 // sh must hold NV * (BLOCK/64) doubles.  Two barriers.
 template <int NV, int BLOCK>

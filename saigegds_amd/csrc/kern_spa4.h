@@ -325,7 +325,7 @@ spa4_moments(RowsRef rr, DevModel md, int nseg, int tier, int btop, int v0, int 
 			// the wave's LDS queue and is shared out evenly, 64 carriers a round.  (abl & 256: everything
 			// the queue holds goes through it -- measured, no faster: filling the queue costs what the
 			// idle lane-steps do.)
-			const int ctot = wave_sum_i(__popc(lo) + __popc(hi));
+			const int ctot = wave_total_i(__popc(lo) + __popc(hi));
 			const int T = (abl & 256) ? max(0, (ctot - spa4_qcap(K) + WAVE - 1) / WAVE) : (ctot + WAVE - 1) / WAVE;
 			// exactly T fetches, none of them inside a branch of the loop body
 			Car ca, cb;
@@ -347,13 +347,8 @@ spa4_moments(RowsRef rr, DevModel md, int nseg, int tier, int btop, int v0, int 
 			}
 			if (__ballot((lo | hi) != 0)) {
 				const int rem = __popc(lo) + __popc(hi);
-				int incl = rem;
-#pragma unroll
-				for (int o = 1; o < WAVE; o <<= 1) {
-					const int up = __shfl_up(incl, o, WAVE);
-					if (lane >= o) incl += up;
-				}
-				const int nq = min(__shfl(incl, WAVE - 1, WAVE), spa4_qcap(K));
+				const int incl = wave_scan_incl_i(rem);
+				const int nq = min(__builtin_amdgcn_readlane(incl, WAVE - 1), spa4_qcap(K));
 				int o2 = incl - rem;
 				while ((lo | hi) != 0 && o2 < spa4_qcap(K)) {
 					const bool inlo = lo != 0;
@@ -391,13 +386,12 @@ spa4_moments(RowsRef rr, DevModel md, int nseg, int tier, int btop, int v0, int 
 				}
 			}
 			const int idx = wave_reduce_scatter(acc, lane);
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o, WAVE));
+			gmax = wave_max_nonneg_to_last(gmax);
 			// [variant][segment][NS]: the sums of a (variant, segment) leave in one store, and spa4_solve reads a
 			// variant's segments as one contiguous run
 			const size_t base = ((size_t)(vb + vl) * nseg + seg) * NS;
 			if (!(lane & (NS - 1 > 16 ? 1 : 3)) && idx < NS - 1) segpart[base + idx] = acc[0];
-			if (lane == 1) segpart[base + (NS - 1)] = gmax;
+			if (lane == WAVE - 1) segpart[base + (NS - 1)] = gmax;
 		}
 	}
 	spa4_queue_done(cursor);
@@ -494,13 +488,12 @@ spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, in
 				}
 			}
 			const int idx = wave_reduce_scatter(acc, lane);
-#pragma unroll
-			for (int o = 32; o > 0; o >>= 1) gmax = fmax(gmax, __shfl_xor(gmax, o, WAVE));
+			gmax = wave_max_nonneg_to_last(gmax);
 			// [variant][segment][NS]: the sums of a (variant, segment) leave in one store, and spa4_solve reads a
 			// variant's segments as one contiguous run
 			const size_t base = ((size_t)(vb + vl) * nseg + seg) * NS;
 			if (!(lane & (NS - 1 > 16 ? 1 : 3)) && idx < NS - 1) segpart[base + idx] = acc[0];
-			if (lane == 1) segpart[base + (NS - 1)] = gmax;
+			if (lane == WAVE - 1) segpart[base + (NS - 1)] = gmax;
 		}
 	}
 	spa4_queue_done(cursor);
