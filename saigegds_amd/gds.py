@@ -365,20 +365,26 @@ class GdsFile:
         return nd is not None
 
     def genotype_dims(self) -> Tuple[int, int]:
-        """(variants, samples) of genotype/data after the checks of ``dosage_alt_packed``."""
+        """(variants, samples) of genotype/data.  A site with more than three alleles takes more than one row
+        of 2-bit codes (SeqArray: ``genotype/@data`` holds the number of rows per variant; the rows are the
+        base-4 digits of the allele index, least significant first, all bits set = missing), so the number of
+        variants is the length of ``@data`` and the row offsets are its running sum (``_geno_rows``)."""
         nd = self.node("genotype/data")
         if nd.cls != "dBit2" or len(nd.dims) != 3:
             raise GdsError("genotype/data: expected dBit2 [variant, sample, ploidy]")
-        M, N, P = nd.dims
+        R, N, P = nd.dims
         if P != 2:
             raise GdsError("only diploid genotypes are supported")
-        if not getattr(nd, "_reps_ok", False):
+        if getattr(nd, "_row0", None) is None:
             if self.node("genotype/@data", silent=True) is not None:
-                reps = np.asarray(self.read("genotype/@data")).reshape(-1)
-                if reps.size and not np.all(reps == 1):
-                    raise GdsError("multi-allelic (>2 bits) genotype storage is not supported")
-            nd._reps_ok = True
-        return M, N
+                reps = np.asarray(self.read("genotype/@data")).reshape(-1).astype(np.int64)
+                if reps.size and (reps.min() < 1 or int(reps.sum()) != R):
+                    raise GdsError("genotype/@data does not add up to the rows of genotype/data")
+            else:
+                reps = np.ones(R, dtype=np.int64)
+            nd._row0 = np.concatenate([[0], np.cumsum(reps)])      # rows of variant v: [_row0[v], _row0[v + 1])
+            nd._multi = bool(reps.size and reps.max() > 1)
+        return int(nd._row0.size - 1), N
 
     # per byte of genotype/data (two samples x two 2-bit allele codes) -> the two samples' dosage codes in
     # the low 4 bits.  $dosage_alt counts every non-reference allele (R/assoc_single.r:69-85 reads SeqArray's
@@ -412,6 +418,10 @@ class GdsFile:
         M, N = self.genotype_dims()
         v0, v1 = max(0, v0), min(M, v1)
         m = v1 - v0
+        nd = self.node("genotype/data")
+        if nd._multi and m > 0 and nd._row0[v1] - nd._row0[v0] != m:
+            return self._dosage_alt_multirow(v0, v1, sample_sel, out, chunk_bytes)
+        r0 = int(nd._row0[v0]) if m > 0 else 0                 # (a range of single-row variants: rows r0 .. r0 + m)
         sel = None if sample_sel is None else np.asarray(sample_sel, dtype=np.int64)
         n_out = N if sel is None else int(sel.size)
         nb = (n_out + 3) // 4
@@ -431,7 +441,7 @@ class GdsFile:
         for a in range(0, m, step):
             b = min(m, a + step)
             k = b - a
-            bits0, bits1 = (v0 + a) * N * 4, (v0 + b) * N * 4
+            bits0, bits1 = (r0 + a) * N * 4, (r0 + b) * N * 4
             data = np.frombuffer(self.raw_range("genotype/data", bits0 // 8, (bits1 + 7) // 8), dtype=np.uint8)
             if native is not None:
                 # libsaigehip's host decoder (sgx_decode_dbit2): rows over host threads, straight into `out`
@@ -457,6 +467,50 @@ class GdsFile:
                     codes = codes[:, sel]
             res[a:b, :nb] = pack_dosage_2bit(codes)
         return res if res.shape[1] == nb else res
+
+    def _dosage_alt_multirow(self, v0, v1, sample_sel, out, chunk_bytes):
+        """The range holds sites of more than three alleles: through the allele indices (numpy; such sites are
+        rare, so this path is not tuned).  Runs of single-row variants inside the range take the fast path."""
+        M, N = self.genotype_dims()
+        nd = self.node("genotype/data")
+        m = v1 - v0
+        sel = None if sample_sel is None else np.asarray(sample_sel, dtype=np.int64)
+        n_out = N if sel is None else int(sel.size)
+        nb = (n_out + 3) // 4
+        if out is None:
+            out = np.zeros((m, nb), dtype=np.uint8)
+        elif out.shape[0] < m or out.shape[1] < nb or out.dtype != np.uint8:
+            raise ValueError("dosage_alt_packed_range: `out` too small")
+        res = out[:m]
+        res[:, nb:] = 0
+        reps = np.diff(nd._row0[v0:v1 + 1])
+        v = v0
+        while v < v1:
+            if reps[v - v0] == 1:
+                e = v
+                while e < v1 and reps[e - v0] == 1:
+                    e += 1
+                self.dosage_alt_packed_range(v, e, sample_sel, res[v - v0:e - v0], chunk_bytes)
+                v = e
+                continue
+            ra, rb = int(nd._row0[v]), int(nd._row0[v + 1])
+            bits0, bits1 = ra * N * 4, rb * N * 4
+            data = np.frombuffer(self.raw_range("genotype/data", bits0 // 8, (bits1 + 7) // 8), dtype=np.uint8)
+            dig = np.empty((data.size, 4), dtype=np.uint8)
+            for q in range(4):
+                dig[:, q] = (data >> (2 * q)) & 3
+            dig = dig.reshape(-1)[(bits0 % 8) // 2:][:(rb - ra) * N * 2].reshape(rb - ra, N, 2).astype(np.int64)
+            idx = np.zeros((N, 2), dtype=np.int64)
+            for k in range(rb - ra):
+                idx |= dig[k] << (2 * k)
+            miss = idx == (1 << (2 * (rb - ra))) - 1
+            codes = ((idx[:, 0] != 0) & ~miss[:, 0]).astype(np.uint8) + ((idx[:, 1] != 0) & ~miss[:, 1])
+            codes[miss[:, 0] | miss[:, 1]] = 3
+            if sel is not None:
+                codes = codes[sel]
+            res[v - v0, :nb] = pack_dosage_2bit(codes[None, :])[0]
+            v += 1
+        return res
 
     def dosage_alt_packed(self) -> Tuple[np.ndarray, int, int]:
         """``$dosage_alt`` of every variant (see ``dosage_alt_packed_range``) -> (packed, N, M)."""

@@ -233,6 +233,42 @@ class GdsWriter:
                 f.write(_u48((22 + len(s)) | (1 << 47)) + _u48(0) + struct.pack("<I", sid) + _u48(len(s)) + s)
 
 
+def write_seqarray_alleles(fn: str, alleles: np.ndarray, sample_id: Optional[Sequence[str]] = None,
+                           compress: str = "none", ra_block: int = _RA_BLOCK):
+    """A SeqArray-style genotype file from allele indices ``alleles`` [M, N, 2] (0 = reference, -1 = missing):
+    a site whose largest index does not fit below the all-ones missing code of n rows takes n + 1 rows of
+    2-bit codes (base-4 digits, least significant row first); ``genotype/@data`` holds the rows per variant.
+    Test generator for sites with more than three alleles."""
+    al = np.asarray(alleles, dtype=np.int64)
+    M, N, _ = al.shape
+    rows, reps = [], []
+    for v in range(M):
+        top = int(al[v].max())
+        n = 1
+        while top >= 4 ** n - 1:
+            n += 1
+        a = np.where(al[v] < 0, 4 ** n - 1, al[v])
+        for k in range(n):
+            rows.append(((a >> (2 * k)) & 3).astype(np.uint8).reshape(-1))          # [N * 2] codes of row k
+        reps.append(n)
+    codes = np.concatenate(rows)
+    pad = (-codes.size) % 4
+    codes = np.concatenate([codes, np.zeros(pad, np.uint8)]).reshape(-1, 4)
+    raw = (codes[:, 0] | (codes[:, 1] << 2) | (codes[:, 2] << 4) | (codes[:, 3] << 6)).astype(np.uint8).tobytes()
+    R = int(np.sum(reps))
+    w = GdsWriter(fn)
+    w.put_attr("FileFormat", "SEQ_ARRAY")
+    sid = [f"s{i + 1}" for i in range(N)] if sample_id is None else [str(x) for x in sample_id]
+    w.add("sample.id", sid, "none")
+    w.add("variant.id", np.arange(1, M + 1), "none")
+    w.add("position", np.arange(1, M + 1) * 100, "none")
+    w.add("chromosome", ["1"] * M, "none")
+    w.add("allele", [",".join("ACGTN"[:1] + "CGTAN"[:1]) if r == 1 else "A,C,G,T,AA,CC" for r in reps], "none")
+    w.add("genotype/data", raw, compress, cls="dBit2", dims=(R, N, 2), ra_block=ra_block)
+    w.add("genotype/@data", np.asarray(reps, dtype=np.uint8).tobytes(), "none", cls="dUInt8", dims=(M,))
+    w.close()
+
+
 def write_seqarray_genotypes(fn: str, packed: np.ndarray, n_samp: int, sample_id: Optional[Sequence[str]] = None,
                              compress: str = "none", chromosome: str = "1", ra_block: int = _RA_BLOCK):
     """A SeqArray-style genotype file from 2-bit dosage rows (``packed``: [M, >= ceil(N / 4)], code = alt-allele

@@ -237,6 +237,34 @@ def test_dosage_alt_counts_every_non_reference_allele():
         assert (v & 3, v >> 2) == (d0, d1), (s0, s1)
 
 
+def test_sites_with_more_than_three_alleles(tmp_path):
+    """genotype/@data > 1: the allele index of such a site takes several rows of 2-bit digits (all bits set =
+    missing); $dosage_alt counts the non-reference alleles whatever their index.  Parity unpinned: the
+    reference's fixtures hold biallelic sites only; the layout is SeqArray's as documented."""
+    from saigegds_amd.gds import GdsFile, unpack_dosage_2bit
+    from saigegds_amd.gds_write import write_seqarray_alleles
+    rng = np.random.default_rng(1)
+    for n in (37, 40):                                   # rows that are and are not whole bytes
+        m = 23
+        al = rng.integers(0, 2, size=(m, n, 2))
+        for v, top in ((3, 3), (4, 5), (10, 14), (11, 15), (17, 40)):       # 2, 2, 2, 3 and 3 rows
+            al[v] = rng.integers(0, top + 1, size=(n, 2))
+            al[v, 0, 0] = top
+        al[rng.random((m, n)) < 0.1] = -1
+        al[5, 7, 1] = -1                                 # one allele missing makes the sample missing
+        want = (al[:, :, 0] > 0).astype(int) + (al[:, :, 1] > 0)
+        want[(al < 0).any(2)] = 3
+        for comp in ("none", "LZMA"):
+            fn = str(tmp_path / f"multi_{n}_{comp}.gds")
+            write_seqarray_alleles(fn, al, compress=comp, ra_block=64)
+            g = GdsFile(fn)
+            assert g.genotype_dims() == (m, n) and g.node("genotype/data").dims[0] == 23 + 1 * 3 + 2 * 2
+            assert np.array_equal(unpack_dosage_2bit(g.dosage_alt_packed_range(0, m), n), want)
+            assert np.array_equal(unpack_dosage_2bit(g.dosage_alt_packed_range(5, 9), n), want[5:9])       # single rows, offset
+            rev = np.arange(n)[::-1]
+            assert np.array_equal(unpack_dosage_2bit(g.dosage_alt_packed_range(2, 13, rev), n), want[2:13, ::-1])
+
+
 def test_scan_blocks_runs_one_thread_per_gpu():
     """The block loop of seqAssocGLMM_SPA with parallel = 2: two scanners work at the same time, every
     block lands at its own offset, a failing block stops the scan with its error."""
