@@ -10,6 +10,8 @@ from __future__ import annotations
 import math
 from typing import Any, Dict, List, Optional, Union
 
+import time
+
 import numpy as np
 
 from .gds import GdsError, GdsFile, pack_dosage_2bit, unpack_dosage_2bit
@@ -179,7 +181,10 @@ def seqAssocGLMM_SPA(gdsfile: Union[str, GdsFile, GenotypeSource], modobj: Any, 
     out = np.empty((n_var, 8), dtype=np.float64)
     valid = np.zeros(n_var, dtype=np.uint8)
     blocks = [(off, min(n_var, off + BLOCK_SIZE)) for off in range(0, n_var, BLOCK_SIZE)]
+    t_loop = time.perf_counter()
     scan_blocks(lambda d: Scanner(mobj, device=d), ngpu, blocks, read_block, kind == "packed", out, valid, timing)
+    if timing is not None:
+        timing["blocks_s"] = time.perf_counter() - t_loop      # handles + every block (decode and scan overlapped)
 
     x = valid.astype(bool)           # R/assoc_single.r:225-234
     if verbose:

@@ -147,6 +147,19 @@ class GdsFile:
                 break
         return b"".join(out)
 
+    def stream_view(self, bid: int, off: int, n: int):
+        """As ``stream_read``, but without a copy where the range lies inside one segment of the stream: a
+        memoryview of the mapped file (the block decoders and ``numpy.frombuffer`` read from it directly, and
+        the page faults of a large uncompressed node are then taken by the decoder's threads, not here)."""
+        pos = 0
+        for p, ln in self._streams[bid]:
+            if pos <= off and off + n <= pos + ln:
+                return memoryview(self.buf)[p + off - pos:p + off - pos + n]
+            pos += ln
+            if pos >= off + n:
+                break
+        return self.stream_read(bid, off, n)
+
     _RA_MAGIC = {b"XZ_RA": "xz", b"ZIP_RA": "zip", b"LZ4_RA": "lz4"}
 
     def _ra_index(self, nd: "GdsNode"):
@@ -178,7 +191,7 @@ class GdsFile:
             raise GdsError(f"{path}: not an array node")
         pipe = nd.pipe.upper()
         if pipe == "":
-            return self.stream_read(nd.data_id, lo, hi - lo)
+            return self.stream_view(nd.data_id, lo, hi - lo)
         if not pipe.endswith("_RA") and "_RA:" not in pipe and "_RA" not in pipe:
             # one compressed stream: no random access -- decode once per file object, not once per block
             with self._lock:
@@ -192,7 +205,7 @@ class GdsFile:
             if ro + rs <= lo or ro >= hi:
                 continue
             if cache.get(path, (-1, b""))[0] != k:
-                blk = _decode_block(nd._ra_kind, self.stream_read(nd.data_id, so, cs), rs)
+                blk = _decode_block(nd._ra_kind, self.stream_view(nd.data_id, so, cs), rs)
                 if len(blk) != rs:
                     raise GdsError("random-access block size mismatch")
                 cache[path] = (k, blk)
