@@ -359,7 +359,7 @@ def test_block_carrier_lists_equal_row_scans(monkeypatch):
 
 
 def test_two_lanes_give_identical_tables():
-    """"lanes" = 2: successive device-resident scans alternate between two streams with their own
+    """"lanes" = 2 .. 4: successive device-resident scans go round-robin over that many streams with their own
     workspace; every block's table must equal the single-lane one, and the totals must add up."""
     import torch
     sm, packed = _synthetic_case(3001, 2400, "binary", 0.05, seed=31)
@@ -369,7 +369,7 @@ def test_two_lanes_give_identical_tables():
         pk = torch.zeros((4, 600, bpv), dtype=torch.uint8, device=dev)
         pk[:, :, :packed.shape[1]] = torch.from_numpy(packed.reshape(4, 600, -1)).to(dev)
         res = {}
-        for lanes in (1, 2):
+        for lanes in (1, 2, 4, 3):
             sc.set_option("lanes", lanes)
             out = torch.full((4, 600, 8), -1.0, dtype=torch.float64, device=dev)
             valid = torch.zeros((4, 600), dtype=torch.uint8, device=dev)
@@ -381,9 +381,10 @@ def test_two_lanes_give_identical_tables():
             assert ncalls == 12 and tot["n_variants"] == 12 * 600
             res[lanes] = (out.cpu().numpy(), valid.cpu().numpy(), tot)
         sc.set_option("lanes", 1)
-    assert np.array_equal(res[1][1], res[2][1])
-    assert np.array_equal(np.nan_to_num(res[1][0], nan=-7.0), np.nan_to_num(res[2][0], nan=-7.0))
-    assert res[1][2]["n_spa"] == res[2][2]["n_spa"] and res[1][2]["n_valid"] == res[2][2]["n_valid"]
+    for lanes in (2, 3, 4):
+        assert np.array_equal(res[1][1], res[lanes][1])
+        assert np.array_equal(np.nan_to_num(res[1][0], nan=-7.0), np.nan_to_num(res[lanes][0], nan=-7.0))
+        assert res[1][2]["n_spa"] == res[lanes][2]["n_spa"] and res[1][2]["n_valid"] == res[lanes][2]["n_valid"]
     ref, ref_valid = _oracle(sm).scan_2bit(packed)
     assert_table_close(res[2][0].reshape(-1, 8), res[2][1].reshape(-1), ref, ref_valid, what="lanes=2")
 
