@@ -86,15 +86,18 @@ __device__ __forceinline__ void s3_unpack_op(uint32_t w, uint32_t &w4, s3_v4i &v
 // LDS per workgroup: (DB + 1) x 4 NBF + (DA + 1) x NC NAF KiB.
 // ABL (timing tool only, wrong results): 1 no unpack/MFMA, 2 no row DMA, 4 no B DMA, 8 no LDS reads of B,
 //   16 clock stamps (s_memtime / s_memrealtime per workgroup behind the slabs)
-template <int NBF, int NAF, int NC, int NLA, int NLB, int DA, int DB, int ABL = 0>
+template <int NBF, int NAF, int NC, int NLA, int NLB, int DA, int DB, int ABL = 0, int NCB = 1, int NBUF_ = 2>
 __global__ void __launch_bounds__(64 * (NC + NLA + NLB), (NC + NLA + NLB + 3) / 4)
 score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3Plan pl, int *__restrict__ out, unsigned long long *__restrict__ stamps)
 {
 #if __HIP_DEVICE_COMPILE__      /* (the host pass only needs the stub; it does not know the buffer-resource builtins) */
+	static_assert(NC % NCB == 0 && NCB >= 1 && NCB <= 4, "consumer waves = variant groups x column groups");
+	constexpr int NCV = NC / NCB;                             // variant groups: consumer wave wid = (vg, cg) = (wid / NCB, wid % NCB)
+	constexpr int NBWMAX = (NBF + NCB - 1) / NCB;             // B fragments of a column group (the last group may hold fewer)
 	constexpr int NCOL = 16 * NBF;
 	constexpr int TILE_BYTES = 16 * NCOL * 16;
 	constexpr int NPB = TILE_BYTES / 1024;                    // KiB pieces of a B tile = 4 NBF
-	constexpr int NPA = NC * NAF;                             // KiB pieces of a tile's rows
+	constexpr int NPA = NCV * NAF;                            // KiB pieces of a tile's rows
 	constexpr int RA = DA + 1, RB = DB + 1;                   // ring slots
 	constexpr int SLOT_A = NPA * 1024;
 	static_assert(DA >= 1 && DB >= 1, "at least one tile ahead");
@@ -193,129 +196,174 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 
 	// -------------------------------------------------------------------- consumer
 	const int r = lane & 15, kg = lane >> 4;
+	const int vg = __builtin_amdgcn_readfirstlane(wid / NCB), cgr = __builtin_amdgcn_readfirstlane(wid % NCB);
 	// LDS byte addresses of this lane's 16 B of a row piece and of its B fragment (sample group 4 kg, column r)
 	const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s3_smem;
-	const uint32_t ring_lds = smem_lds + RB * TILE_BYTES + wid * (NAF * 1024) + lane * 16;
-	const uint32_t bt_lds = smem_lds + (4 * kg * NCOL + r) * 16;
+	const uint32_t ring_lds = smem_lds + RB * TILE_BYTES + vg * (NAF * 1024) + lane * 16;
 
-	s3_v4i acc[NAF][NBF];
-#pragma unroll
-	for (int f = 0; f < NAF; f++)
-#pragma unroll
-		for (int b = 0; b < NBF; b++) acc[f][b] = (s3_v4i){0, 0, 0, 0};
+	// The body of a consumer wave of column group CG: B fragments [B0, B0 + NBW) of the tile against the NAF row
+	// pieces of its variant group.  With NCB > 1 the waves of a variant group read the SAME row pieces and unpack
+	// them redundantly, each multiplying them into its own share of the columns: a wave's LDS reads per MFMA fall
+	// from (NAF + 4 NBF) / (4 NAF NBF) KiB to (NAF' + 4 NBF / NCB) / (4 NAF' NBF / NCB) with NAF' = NCB NAF pieces
+	// at the same number of accumulators -- at K >= 9 the LDS port (B reads + the DMA's writes), not the matrix
+	// pipe, was what the one-column-group form waited for.
+	auto consume = [&](auto CG) {
+		constexpr int cg = decltype(CG)::value;
+		constexpr int B0 = cg * NBWMAX;
+		constexpr int NBW = (NBF - B0 < NBWMAX) ? NBF - B0 : NBWMAX;
+		constexpr bool HASB1 = B0 + NBW == NBF;                 // the bit-1 fragment is the LAST of the tile
+		static_assert(NBW >= 1, "empty column group");
+		const uint32_t bt_lds = smem_lds + (4 * kg * NCOL + r) * 16 + B0 * 256;
 
-	// B fragments are read one chunk (<= BCH fragments) ahead of the MFMAs that use them; per dword step u the
-	// NAF NBF MFMAs run fragment-major (a B fragment feeds NAF consecutive MFMAs) and the 9 NAF unpack
-	// operations -- the b1 planes of this step, then the value planes of the next -- are dealt out evenly
-	// behind them, each group fenced so that the compiler keeps the order.
-	constexpr int BCH = NBF <= 4 ? NBF : (NBF >= 9 ? 2 : (NBF % 3 == 0 ? 3 : 4));
-	// with many B fragments the unpack is a few per cent of a step: one set of value planes, made at the
-	// step's start, leaves the registers to the accumulators
-	constexpr bool PIPE = NBF <= 8;
-	constexpr int NCH = (NBF + BCH - 1) / BCH;              // chunks per dword step
-	constexpr int NM = NAF * NBF;                           // MFMAs per dword step
-	constexpr int NV = 4 * NAF, NW = 5 * NAF;               // b1 operations of a step, value operations of the next
-
-	int sa = 0, sb = 0;        // ring slots of the current tile (rows, B)
-	while (pc.k < nk) {
-		__builtin_amdgcn_sched_barrier(0);
-		__builtin_amdgcn_s_barrier();
-		__builtin_amdgcn_sched_barrier(0);
-		// (LDS reads by inline asm with counted lgkmcnt waits: behind an LDS-DMA the compiler puts vmcnt(0) in
-		// front of every LDS read it can see)
-		const uint32_t a_addr = ring_lds + (uint32_t)(sa * SLOT_A);
-		const uint32_t b_addr = bt_lds + (uint32_t)(sb * TILE_BYTES);
-		s3_v4i aw[NAF];
-		s3_static_for<0, NAF>([&](auto F) { constexpr int f = decltype(F)::value; S3_DS_READ(aw[f], a_addr, f * 1024); });
-		s3_v4i bf[2][BCH];
-		auto read_chunk = [&](auto CI) {
-			constexpr int ci = decltype(CI)::value, u = ci / NCH, b0 = (ci % NCH) * BCH;
-			s3_static_for<0, BCH>([&](auto J) {
-				constexpr int j = decltype(J)::value;
-				if constexpr (b0 + j < NBF) {
-					if (ABL & 8) bf[ci & 1][j] = (s3_v4i){u, j, r, sa};
-					else S3_DS_READ(bf[ci & 1][j], b_addr, u * NCOL * 16 + (b0 + j) * 256);
-				}
-			});
-		};
-		constexpr int nread_last = NBF - (NCH - 1) * BCH;       // fragments of a dword step's last chunk
-		read_chunk(std::integral_constant<int, 0>());
-		// the row pieces are back (the first B chunk may still be in flight): value planes of dword 0
-		if (!(ABL & 8)) { S3_LGKM_WAIT(BCH < NBF ? BCH : NBF, aw[0]); } else { S3_LGKM_WAIT(0, aw[0]); }
+		s3_v4i acc[NAF][NBW];
 #pragma unroll
-		for (int f = 1; f < NAF; f++) S3_TIE(aw[f]);
-		s3_v4i val[PIPE ? 2 : 1][NAF], b1[NAF];
-		uint32_t w4[PIPE ? 2 : 1][NAF];       // the dword shifted by 4: of the current dword (its b1 planes) and of the next (its value planes)
-		if (!(ABL & 1)) {
-			s3_static_for<0, NW>([&](auto O) {
-				constexpr int o = decltype(O)::value, f = o / 5, op = o % 5;
-				s3_unpack_op<op>((uint32_t)aw[f][0], w4[0][f], val[0][f], b1[f]);
-			});
-		}
-		__builtin_amdgcn_sched_barrier(0);
-		s3_static_for<0, 4>([&](auto U) {
-			constexpr int u = decltype(U)::value;
-			constexpr int vb = PIPE ? (u & 1) : 0, vn = PIPE ? ((u + 1) & 1) : 0;      // value-plane sets of this dword / the next
-			if constexpr (!PIPE && u > 0) {
-				if (!(ABL & 1)) {
-					s3_static_for<0, NW>([&](auto O) {
-						constexpr int o = decltype(O)::value, f = o / 5, op = o % 5;
-						s3_unpack_op<op>((uint32_t)aw[f][u], w4[0][f], val[0][f], b1[f]);
-					});
-				}
-				__builtin_amdgcn_sched_barrier(0);
+		for (int f = 0; f < NAF; f++)
+#pragma unroll
+			for (int b = 0; b < NBW; b++) acc[f][b] = (s3_v4i){0, 0, 0, 0};
+
+		// B fragments are read one chunk (<= BCH fragments) ahead of the MFMAs that use them; per dword step u the
+		// NAF NBW MFMAs run fragment-major (a B fragment feeds NAF consecutive MFMAs) and the unpack operations --
+		// the b1 planes of this step, then the value planes of the next -- are dealt out behind them, each group
+		// fenced so that the compiler keeps the order.
+		constexpr int BCH = NBUF_ > 2 ? 1 : NCB > 1 ? (NBW <= 2 ? NBW : 2) : (NBF <= 4 ? NBF : (NBF >= 9 ? 2 : (NBF % 3 == 0 ? 3 : 4)));
+		// NBUF register buffers of one chunk each: the reads run NBUF - 1 chunks ahead of the MFMAs.  (With one
+		// consumer wave per SIMD and all of them reading in step behind the tile barrier an LDS read takes ~270
+		// cycles to come back: one chunk of two fragments ahead = 2 NAF MFMAs is not enough at NAF <= 6.)
+		constexpr int NBUF = NBUF_;
+		// PIPE: two sets of value planes, the next dword's made evenly between ALL MFMAs of the current one (few
+		// fragments: the unpack is a large share of a step).  Otherwise ONE set leaves the registers to the
+		// accumulators, and the next dword's planes of row piece f are made right behind the last MFMA that reads
+		// the current ones (those of the wave's last value fragment), under the MFMAs that follow.
+		constexpr bool PIPE = NCB == 1 && NBF <= 8;
+		constexpr int NCH = (NBW + BCH - 1) / BCH;              // chunks per dword step
+		constexpr int NM = NAF * NBW;                           // MFMAs per dword step
+		constexpr int NV = HASB1 ? 4 * NAF : 0, NW = 5 * NAF;   // b1 operations of a step, value operations of the next
+		constexpr int BLV = HASB1 ? NBW - 2 : NBW - 1;          // the wave's last value fragment (-1: none)
+		// b1 planes of this dword: dealt over the MFMAs before the b1 fragment -- without PIPE before the last value
+		// fragment, whose slots carry the next dword's value planes (they overwrite w4)
+		constexpr int MB = HASB1 ? ((!PIPE && NBW >= 3) ? (NBW - 2) * NAF : (NBW - 1) * NAF) : 0;
+		static_assert(!HASB1 || NBW >= 2 || NCB == 1, "a column group of the b1 fragment alone has no slot for its unpack");
+
+		int sa = 0, sb = 0;        // ring slots of the current tile (rows, B)
+		while (pc.k < nk) {
+			__builtin_amdgcn_sched_barrier(0);
+			__builtin_amdgcn_s_barrier();
+			__builtin_amdgcn_sched_barrier(0);
+			// (LDS reads by inline asm with counted lgkmcnt waits: behind an LDS-DMA the compiler puts vmcnt(0) in
+			// front of every LDS read it can see)
+			const uint32_t a_addr = ring_lds + (uint32_t)(sa * SLOT_A);
+			const uint32_t b_addr = bt_lds + (uint32_t)(sb * TILE_BYTES);
+			s3_v4i aw[NAF];
+			s3_static_for<0, NAF>([&](auto F) { constexpr int f = decltype(F)::value; S3_DS_READ(aw[f], a_addr, f * 1024); });
+			s3_v4i bf[NBUF][BCH];
+			auto read_chunk = [&](auto CI) {
+				constexpr int ci = decltype(CI)::value, u = ci / NCH, b0 = (ci % NCH) * BCH;
+				s3_static_for<0, BCH>([&](auto J) {
+					constexpr int j = decltype(J)::value;
+					if constexpr (b0 + j < NBW) {
+						if (ABL & 8) bf[ci % NBUF][j] = (s3_v4i){u, j, r, sa};
+						else S3_DS_READ(bf[ci % NBUF][j], b_addr, u * NCOL * 16 + (b0 + j) * 256);
+					}
+				});
+			};
+			constexpr int nread_last = NBW - (NCH - 1) * BCH;       // fragments of a dword step's last chunk
+			// fragment reads of chunks [c0, c1) of the tile
+			auto nreads = [](int c0, int c1) constexpr { int n = 0; for (int c = c0; c < c1 && c < 4 * NCH; c++) n += (c % NCH == NCH - 1) ? nread_last : BCH; return n; };
+			s3_static_for<0, NBUF - 1>([&](auto C) { if constexpr (decltype(C)::value < 4 * NCH) read_chunk(C); });
+			// the row pieces are back (the first B chunks may still be in flight): value planes of dword 0
+			if (!(ABL & 8)) { S3_LGKM_WAIT(nreads(0, NBUF - 1), aw[0]); } else { S3_LGKM_WAIT(0, aw[0]); }
+#pragma unroll
+			for (int f = 1; f < NAF; f++) S3_TIE(aw[f]);
+			s3_v4i val[PIPE ? 2 : 1][NAF], b1[NAF];
+			uint32_t w4[PIPE ? 2 : 1][NAF];       // the dword shifted by 4: of the current dword (its b1 planes) and of the next (its value planes)
+			// (without PIPE only those of row piece 0: piece f + 1 follows behind the first MFMA of piece f)
+			if (!(ABL & 1)) {
+				s3_static_for<0, (PIPE ? NW : 5)>([&](auto O) {
+					constexpr int o = decltype(O)::value, f = o / 5, op = o % 5;
+					s3_unpack_op<op>((uint32_t)aw[f][0], w4[0][f], val[0][f], b1[f]);
+				});
 			}
-			s3_static_for<0, NM>([&](auto MI) {
-				constexpr int m = decltype(MI)::value, b = m / NAF, f = m % NAF, ch = b / BCH, ci = u * NCH + ch, j = b % BCH;
-				if constexpr (f == 0 && j == 0) {
-					// entering a chunk: start the next one, then wait for this one
-					if constexpr (ci + 1 < 4 * NCH) read_chunk(std::integral_constant<int, ci + 1>());
-					constexpr int inflight = (ci + 1 < 4 * NCH && !(ABL & 8)) ? ((ci + 1) % NCH == NCH - 1 ? nread_last : BCH) : 0;
-					constexpr int nb = (ch == NCH - 1) ? nread_last : BCH;
-					S3_LGKM_WAIT(inflight, bf[ci & 1][0]);
+			__builtin_amdgcn_sched_barrier(0);
+			// Without PIPE the dword step's LAST chunk runs piece-major when it holds two fragments (both are in
+			// registers): the planes of piece f are free two MFMAs earlier, and their replacement is spread
+			// over two slots instead of five operations behind one MFMA.
+			constexpr bool FM = !PIPE && BCH == 2 && nread_last == 2;
+			constexpr int M0 = (NCH - 1) * BCH * NAF;              // first slot of the last chunk
+			s3_static_for<0, 4>([&](auto U) {
+				constexpr int u = decltype(U)::value;
+				constexpr int vb = PIPE ? (u & 1) : 0, vn = PIPE ? ((u + 1) & 1) : 0;      // value-plane sets of this dword / the next
+				s3_static_for<0, NM>([&](auto MI) {
+					constexpr int m = decltype(MI)::value;
+					constexpr bool fm = FM && m >= M0;
+					constexpr int b = fm ? (NCH - 1) * BCH + (m - M0) % 2 : m / NAF, f = fm ? (m - M0) / 2 : m % NAF;
+					constexpr int ch = b / BCH, ci = u * NCH + ch, j = b % BCH;
+					if constexpr (m == ch * BCH * NAF) {
+						// entering a chunk: start the one NBUF - 1 ahead, then wait for this one
+						if constexpr (ci + NBUF - 1 < 4 * NCH) read_chunk(std::integral_constant<int, ci + NBUF - 1>());
+						constexpr int inflight = (ABL & 8) ? 0 : nreads(ci + 1, ci + NBUF);
+						constexpr int nb = (ch == NCH - 1) ? nread_last : BCH;
+						S3_LGKM_WAIT(inflight, bf[ci % NBUF][0]);
 #pragma unroll
-					for (int jj = 1; jj < nb; jj++) S3_TIE(bf[ci & 1][jj]);
-				}
-				if (ABL & 1) { if (f == 0) acc[0][b][1] ^= bf[ci & 1][j][0] ^ aw[b % NAF][u]; }
-				else if (b == NBF - 1) acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1[f], bf[ci & 1][j], acc[f][b], 0, 0, 0);
-				else acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(val[vb][f], bf[ci & 1][j], acc[f][b], 0, 0, 0);
-				if (!(ABL & 1)) {
-					// b1 planes of this dword: all dealt before the first MFMA of the b1 fragment
-					constexpr int MB = (NBF - 1) * NAF;
-					if constexpr (m < MB) {
-						s3_static_for<m * NV / MB, (m + 1) * NV / MB>([&](auto O) {
-							constexpr int o = decltype(O)::value, ff = o / 4, op = 5 + o % 4;
-							s3_unpack_op<op>((uint32_t)aw[ff][u], w4[vb][ff], val[vb][ff], b1[ff]);
-						});
+						for (int jj = 1; jj < nb; jj++) S3_TIE(bf[ci % NBUF][jj]);
 					}
-					// value planes of the next dword
-					if constexpr (PIPE && u < 3) {
-						s3_static_for<m * NW / NM, (m + 1) * NW / NM>([&](auto O) {
-							constexpr int o = decltype(O)::value, ff = o / 5, op = o % 5;
-							s3_unpack_op<op>((uint32_t)aw[ff][u + 1], w4[vn][ff], val[vn][ff], b1[ff]);
-						});
+					if (ABL & 1) { if (f == 0) acc[0][b][1] ^= bf[ci % NBUF][j][0] ^ aw[b % NAF][u]; }
+					else if (HASB1 && b == NBW - 1) acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1[f], bf[ci % NBUF][j], acc[f][b], 0, 0, 0);
+					else acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(val[vb][f], bf[ci % NBUF][j], acc[f][b], 0, 0, 0);
+					if (!(ABL & 1)) {
+						// value planes of the tile's first dword, row piece f + 1
+						if constexpr (!PIPE && u == 0 && b == 0 && f + 1 < NAF) {
+							s3_static_for<0, 5>([&](auto O) {
+								constexpr int op = decltype(O)::value;
+								s3_unpack_op<op>((uint32_t)aw[f + 1][0], w4[0][f + 1], val[0][f + 1], b1[f + 1]);
+							});
+						}
+						if constexpr (m < MB) {
+							s3_static_for<m * NV / MB, (m + 1) * NV / MB>([&](auto O) {
+								constexpr int o = decltype(O)::value, ff = o / 4, op = 5 + o % 4;
+								s3_unpack_op<op>((uint32_t)aw[ff][u], w4[vb][ff], val[vb][ff], b1[ff]);
+							});
+						}
+						// value planes of the next dword
+						if constexpr (PIPE && u < 3) {
+							s3_static_for<m * NW / NM, (m + 1) * NW / NM>([&](auto O) {
+								constexpr int o = decltype(O)::value, ff = o / 5, op = o % 5;
+								s3_unpack_op<op>((uint32_t)aw[ff][u + 1], w4[vn][ff], val[vn][ff], b1[ff]);
+							});
+						}
+						if constexpr (!PIPE && u < 3) {
+							// behind the last MFMA that reads val[f] (that of fragment BLV); with the b1 fragment behind it
+							// in a piece-major chunk: two operations there, three behind the b1 MFMA
+							constexpr int lo = !fm ? ((b == BLV || (BLV < 0 && b == 0)) ? 0 : 5) : (HASB1 ? (j == 0 ? 0 : 2) : (j == 1 ? 0 : 5));
+							constexpr int hi = !fm ? 5 : (HASB1 && j == 0 ? 2 : 5);
+							s3_static_for<lo, hi>([&](auto O) {
+								constexpr int op = decltype(O)::value;
+								s3_unpack_op<op>((uint32_t)aw[f][u + 1], w4[0][f], val[0][f], b1[f]);
+							});
+						}
 					}
-				}
-				__builtin_amdgcn_sched_barrier(0);
+					__builtin_amdgcn_sched_barrier(0);
+				});
 			});
-		});
-		if (pc.t + 1 == pc.t1) {
-			// the item is complete: its slab [wave][f][b][reg][lane] leaves by plain stores (256 B per instruction)
-			int *dst = out + ((size_t)pc.id * NC + wid) * (NAF * NBF * 256) + lane;
+			if (pc.t + 1 == pc.t1) {
+				// the item is complete: its slab [wave][f][b][reg][lane] leaves by plain stores (256 B per instruction)
+				int *dst = out + ((size_t)pc.id * NC + wid) * (NAF * NBWMAX * 256) + lane;
 #pragma unroll
-			for (int f = 0; f < NAF; f++)
+				for (int f = 0; f < NAF; f++)
 #pragma unroll
-				for (int b = 0; b < NBF; b++)
+					for (int b = 0; b < NBW; b++)
 #pragma unroll
-					for (int reg = 0; reg < 4; reg++) {
-						dst[((f * NBF + b) * 4 + reg) * 64] = acc[f][b][reg];
-						acc[f][b][reg] = 0;
-					}
+						for (int reg = 0; reg < 4; reg++) {
+							dst[((f * NBWMAX + b) * 4 + reg) * 64] = acc[f][b][reg];
+							acc[f][b][reg] = 0;
+						}
+			}
+			pos_next(pc);
+			sa = sa + 1 == RA ? 0 : sa + 1;
+			sb = sb + 1 == RB ? 0 : sb + 1;
 		}
-		pos_next(pc);
-		sa = sa + 1 == RA ? 0 : sa + 1;
-		sb = sb + 1 == RB ? 0 : sb + 1;
-	}
+	};
+	if constexpr (NCB == 1) consume(std::integral_constant<int, 0>());
+	else s3_static_for<0, NCB>([&](auto CG) { if (cgr == decltype(CG)::value) consume(CG); });
 	if ((ABL & 16) && tid == 0) {
 		stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0;
 		stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - sr0;
@@ -682,14 +730,20 @@ s3_t3_sum_kernel(size_t n, const long long *__restrict__ part, long long *__rest
 
 // ---- the item slabs of score3_kernel -> one row of limb sums per variant (the layout the epilogue reads:
 // accbuf[v * stride + 16 b + r]).  grid = (elements of a variant tile's slab / 256, variant tiles).
+// A slab is [consumer wave = (variant group, column group)][f][b < NBW][reg][lane]: NCW waves, NCB column groups
+// of NBW = ceil(NBF / NCB) fragment slots each (the last group's spare slots are never written).
 __global__ void __launch_bounds__(256)
-s3_reduce_kernel(S3Plan pl, int M, int NCW, int NAF, int NBF, const int *__restrict__ slabs, int *__restrict__ accbuf, int stride)
+s3_reduce_kernel(S3Plan pl, int M, int NCW, int NAF, int NBF, int NCB, const int *__restrict__ slabs, int *__restrict__ accbuf, int stride)
 {
-	const int e = blockIdx.x * 256 + threadIdx.x, per = NCW * NAF * NBF * 256, vtile = blockIdx.y;
+	const int NBW = (NBF + NCB - 1) / NCB;
+	const int e = blockIdx.x * 256 + threadIdx.x, per = NCW * NAF * NBW * 256, vtile = blockIdx.y;
 	if (e >= per) return;
-	const int lane = e & 63, reg = (e >> 6) & 3, fb = e >> 8;           // fb = (wave NAF + f) NBF + b
-	const int b = fb % NBF, wf = fb / NBF;                              // wf = wave NAF + f
-	const int v = (vtile * pl.fpw + wf) * 16 + (lane >> 4) * 4 + reg;
+	const int lane = e & 63, reg = (e >> 6) & 3, fb = e >> 8;           // fb = (wave NAF + f) NBW + b
+	const int bw = fb % NBW, wf = fb / NBW;                             // wf = wave NAF + f
+	const int wave = wf / NAF, f = wf - wave * NAF;
+	const int b = (wave % NCB) * NBW + bw;                              // fragment of the tile
+	if (b >= NBF) return;
+	const int v = (vtile * pl.fpw + (wave / NCB) * NAF + f) * 16 + (lane >> 4) * 4 + reg;
 	if (v >= M) return;
 	int sum = 0;
 	for (int g = 0; g < pl.ng; g++) {

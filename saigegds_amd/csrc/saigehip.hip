@@ -1027,12 +1027,17 @@ extern "C" int sgx_block_load_dev(sgx_handle *h, sgx_block *b, const uint8_t *pa
 extern "C" size_t sgx_block_variants(const sgx_block *b) { return b ? b->M : 0; }
 
 // Per NBF the instantiation of score3_kernel: fragments per consumer wave, consumer / row-loader / B-loader
-// waves, tiles ahead (rows / B) -- what fits 160 KiB of LDS and the registers of that many waves, the
-// fastest of the forms measured with tools/score3_bench (tools/README.md).
+// waves, tiles ahead (rows / B), column groups of the consumer waves -- what fits 160 KiB of LDS and the registers
+// of that many waves, the fastest of the forms measured with tools/score3_bench (tools/README.md).  Column groups
+// (two waves sharing the row pieces, each with half of the columns) measured 7 % faster than one group at 12
+// fragments on the tool's random operands and 4 % SLOWER in the scan (real rows are mostly zero codes: the chip
+// clocks higher and the doubled unpack then costs more than the saved LDS reads): one group everywhere.
 #define S3_FOR_EACH_NBF(X) \
-	X(2, 4, 8, 3, 1, 3, 2) X(3, 4, 8, 3, 1, 3, 1) X(4, 4, 8, 3, 1, 2, 2) X(5, 3, 8, 3, 1, 3, 1) X(6, 3, 8, 3, 1, 3, 1) \
-	X(7, 4, 4, 2, 2, 3, 1) X(8, 4, 4, 2, 2, 3, 1) X(9, 4, 4, 2, 2, 3, 1) X(10, 4, 4, 2, 2, 3, 1) X(11, 4, 4, 2, 2, 3, 1) \
-	X(12, 3, 4, 2, 2, 3, 1) X(13, 3, 4, 2, 2, 3, 1) X(14, 2, 4, 2, 2, 3, 1) X(15, 2, 4, 2, 2, 3, 1) X(16, 2, 4, 2, 2, 3, 1)
+	X(2, 4, 8, 3, 1, 3, 2, 1) X(3, 4, 8, 3, 1, 3, 1, 1) X(4, 4, 8, 3, 1, 2, 2, 1) X(5, 3, 8, 3, 1, 3, 1, 1) X(6, 3, 8, 3, 1, 3, 1, 1) \
+	X(7, 4, 4, 2, 2, 3, 1, 1) X(8, 4, 4, 2, 2, 3, 1, 1) X(9, 4, 4, 2, 2, 3, 1, 1) X(10, 4, 4, 2, 2, 3, 1, 1) X(11, 4, 4, 2, 2, 3, 1, 1) \
+	X(12, 3, 4, 2, 2, 3, 1, 1) X(13, 3, 4, 2, 2, 3, 1, 1) X(14, 2, 4, 2, 2, 3, 1, 1) X(15, 2, 4, 2, 2, 3, 1, 1) X(16, 2, 4, 2, 2, 3, 1, 1)
+// (SAIGEHIP_S3_ALT=1, timing experiments: the other candidate of a fragment count, key 100 + NBF)
+#define S3_FOR_EACH_ALT(X) X(112, 6, 4, 2, 2, 3, 1, 2)
 
 template <typename T>
 static int ensure_buf(sgx_handle *h, T **p, size_t *cap, size_t need)
@@ -1057,7 +1062,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	const int NBF = h->mf_nbfv[0] + 1;
 	const int grid = std::max(8, h->n_cu & ~7);
 	S3Plan pl{};
-	int NCW = 0, NAFW = 0;
+	int NCW = 0, NAFW = 0, NCBW = 1;
 	HIPCHK(hipStreamWaitEvent(st, b->ready, 0));
 	HIPCHK(hipMemsetAsync(h->counters, 0, 24 * sizeof(int), st));
 	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 8 * sizeof(int), st));
@@ -1066,11 +1071,16 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	if (rc) return rc;
 	rc = ensure_buf(h, &h->s3_ovf, &h->s3_ovf_cap, M);
 	if (rc) return rc;
-	// sums over the missing samples, on the side stream: a pass bound by L2 latency whose workgroups fit
-	// beside the contraction kernel's (K <= 7), so it costs the step nothing
-	HIPCHK(hipEventRecord(h->s3_fork, st));
+	// sums over the missing samples, on the side stream, beside the contraction kernel.  The pass goes FIRST: with
+	// few fragments (3 waves of ~154 registers per SIMD) it finds no room beside a resident contraction workgroup
+	// and would wait for the kernel's end.  From 7 fragments on (2 waves of <= 216 registers) one wave of the pass
+	// fits per SIMD, but launched second and running in the kernel's shadow it slows the kernel by what it saves
+	// (K = 13, same box: 6.13 / 6.20 ms per step first, 6.23 / 6.23 after; SAIGEHIP_T3_ORDER=1 for the experiment).
+	static const int t3_order = [] { const char *e = getenv("SAIGEHIP_T3_ORDER"); return e ? atoi(e) : 0; }();   // 0 first, 1 after
+	const bool t3_after = t3_order == 1;
+	HIPCHK(hipEventRecord(h->s3_fork, st));                  // (the side stream starts where this stream stands NOW)
 	HIPCHK(hipStreamWaitEvent(h->s3_side, h->s3_fork, 0));
-	{
+	auto launch_t3 = [&]() -> int {
 		hipStream_t s2 = h->s3_side;
 		const int PP = md.P <= 8 ? 8 : md.P <= 16 ? 16 : md.P <= 32 ? 32 : 64;
 		const int tpw = 64 / PP;
@@ -1084,16 +1094,21 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 		hipLaunchKernelGGL(s3_t3_sum_kernel, dim3((unsigned)((n3e + 255) / 256)), dim3(256), 0, s2, n3e, h->s3_t3, h->s3_t3 + (size_t)S3_NR * n3e);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(h->s3_join, s2));
-	}
-	switch (NBF) {
-#define S3CASE(NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_)                                                        \
-	case NBF_: {                                                                                          \
-		NCW = NC_; NAFW = NAF_;                                                                           \
-		pl = s3_plan(M, b->ntile, grid, NAF_ * NC_);                                                      \
-		rc = ensure_buf(h, &h->s3_slabs, &h->s3_slabs_cap, (size_t)pl.ng * pl.ipg * NC_ * NAF_ * NBF_ * 256); \
+		return SGX_OK;
+	};
+	if (!t3_after) { rc = launch_t3(); if (rc) return rc; }
+	static const bool s3_alt = [] { const char *e = getenv("SAIGEHIP_S3_ALT"); return e && e[0] == '1'; }();
+	switch ((s3_alt && NBF == 12) ? 100 + NBF : NBF) {
+#define S3CASE(KEY_, NAF_, NC_, NLA_, NLB_, DA_, DB_, NCB_)                                                  \
+	case KEY_: {                                                                                          \
+		constexpr int NBF_ = KEY_ % 100;                                                                  \
+		NCW = NC_; NAFW = NAF_; NCBW = NCB_;                                                              \
+		constexpr int NBW_ = (NBF_ + NCB_ - 1) / NCB_, NCV_ = NC_ / NCB_;                                  \
+		pl = s3_plan(M, b->ntile, grid, NAF_ * NCV_);                                                     \
+		rc = ensure_buf(h, &h->s3_slabs, &h->s3_slabs_cap, (size_t)pl.ng * pl.ipg * NC_ * NAF_ * NBW_ * 256); \
 		if (rc) return rc;                                                                                \
-		const size_t lds = ((size_t)(DB_ + 1) * 4 * NBF_ + (size_t)(DA_ + 1) * NC_ * NAF_) * 1024;        \
-		auto kern = score3_kernel<NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_, 0>;                               \
+		const size_t lds = ((size_t)(DB_ + 1) * 4 * NBF_ + (size_t)(DA_ + 1) * NCV_ * NAF_) * 1024;       \
+		auto kern = score3_kernel<NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_, 0, NCB_>;                         \
 		if (!h->s3_attr[NBF_]) {                                                                          \
 			HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
 			h->s3_attr[NBF_] = true;                                                                      \
@@ -1105,14 +1120,16 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 		h->evk_set = true;                                                                                \
 	} break;
 		S3_FOR_EACH_NBF(S3CASE)
+		S3_FOR_EACH_ALT(S3CASE)
 #undef S3CASE
 	default: return fail(SGX_EINVAL, "score3: %d B fragments not supported", NBF);
 	}
 	HIPCHK(hipGetLastError());
+	if (t3_after) { rc = launch_t3(); if (rc) return rc; }
 	{
-		const int per = NCW * NAFW * NBF * 256;
+		const int per = NCW * NAFW * ((NBF + NCBW - 1) / NCBW) * 256;
 		hipLaunchKernelGGL(s3_reduce_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)pl.vt), dim3(256), 0, st,
-			pl, (int)M, NCW, NAFW, NBF, h->s3_slabs, h->mf_acc, ep.acc_stride);
+			pl, (int)M, NCW, NAFW, NBF, NCBW, h->s3_slabs, h->mf_acc, ep.acc_stride);
 	}
 	HIPCHK(hipStreamWaitEvent(st, h->s3_join, 0));
 	const int btop = md.quant ? 0 : (int)(2 * M);

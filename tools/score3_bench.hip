@@ -36,17 +36,18 @@ __global__ void fill_codes(uint32_t *dst, size_t ndw, uint64_t seed)
 
 struct Shape { int N; size_t M; };
 
-template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int ABL>
+template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int ABL, int NCB = 1, int NBUF = 2>
 static float run(const char *name, const uint8_t *A, const uint8_t *Fl, int ntile, size_t M, int wg_per_cu, int n_cu, int *out, size_t out_ints,
 	int reps, S3Plan *plan_out = nullptr)
 {
 	const int grid = n_cu * wg_per_cu;
-	const S3Plan pl = s3_plan(M, ntile, grid, NAF * WAVES);
-	const size_t need = (size_t)pl.ng * pl.ipg * WAVES * NAF * NBF * 256;
+	constexpr int NCV = WAVES / NCB, NBW = (NBF + NCB - 1) / NCB;
+	const S3Plan pl = s3_plan(M, ntile, grid, NAF * NCV);
+	const size_t need = (size_t)pl.ng * pl.ipg * WAVES * NAF * NBW * 256;
 	if (need > out_ints) { fprintf(stderr, "%s: out buffer too small (%zu > %zu)\n", name, need, out_ints); exit(1); }
 	if (plan_out) *plan_out = pl;
-	const size_t lds = ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * WAVES * NAF) * 1024;
-	auto kern = score3_kernel<NBF, NAF, WAVES, NLA, NLB, DA, DB, ABL>;
+	const size_t lds = ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * NCV * NAF) * 1024;
+	auto kern = score3_kernel<NBF, NAF, WAVES, NLA, NLB, DA, DB, ABL, NCB, NBUF>;
 	static unsigned long long *stamps = nullptr;
 	if (!stamps) CK(hipMalloc((void **)&stamps, 16 * 4096));
 	CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -75,8 +76,8 @@ static float run(const char *name, const uint8_t *A, const uint8_t *Fl, int ntil
 			std::sort(c.begin(), c.end());
 			if (!c.empty()) ghz = c[c.size() / 2];
 		}
-		printf("%-40s NBF=%2d NAF=%d NC=%d NL=%d+%d D=%d/%d ABL=%2d  items/grp=%4d f=%2d  %7.3f ms  %6.0f GB/s  %.3f of 8 TB/s",
-			name, NBF, NAF, WAVES, NLA, NLB, DA, DB, ABL, pl.ipg, pl.f, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0);
+		printf("%-40s NBF=%2d NAF=%d NC=%d/%d NL=%d+%d D=%d/%d buf %d ABL=%2d  items/grp=%4d f=%2d  %7.3f ms  %6.0f GB/s  %.3f of 8 TB/s",
+			name, NBF, NAF, WAVES, NCB, NLA, NLB, DA, DB, NBUF, ABL, pl.ipg, pl.f, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0);
 		if (ABL & 16) printf("  clock %.3f GHz", ghz);
 		printf("\n");
 		fflush(stdout);
@@ -85,7 +86,7 @@ static float run(const char *name, const uint8_t *A, const uint8_t *Fl, int ntil
 }
 
 // CPU check: sums of the item slabs per (variant, column) against the direct sum
-template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB>
+template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int NCB = 1, int NBUF = 2>
 static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu)
 {
 	const int ntile = 2 * ((N + 511) / 512);
@@ -122,18 +123,19 @@ static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu)
 	CK(hipMemcpy(dA, hA.data(), abytes, hipMemcpyHostToDevice));
 	CK(hipMemcpy(dF, hF.data(), flbytes, hipMemcpyHostToDevice));
 	const int grid = n_cu * wg_per_cu;
-	const S3Plan pl0 = s3_plan(M, ntile, grid, NAF * WAVES);
-	const size_t oints = (size_t)pl0.ng * pl0.ipg * WAVES * NAF * NBF * 256;
+	constexpr int NCV = WAVES / NCB, NBW = (NBF + NCB - 1) / NCB;
+	const S3Plan pl0 = s3_plan(M, ntile, grid, NAF * NCV);
+	const size_t oints = (size_t)pl0.ng * pl0.ipg * WAVES * NAF * NBW * 256;
 	CK(hipMalloc((void **)&dO, oints * 4));
 	CK(hipMemset(dO, 0xCD, oints * 4));
 	S3Plan pl;
-	run<NBF, NAF, WAVES, NLA, NLB, DA, DB, 0>(name, dA, dF, ntile, M, wg_per_cu, n_cu, dO, oints, 0, &pl);
+	run<NBF, NAF, WAVES, NLA, NLB, DA, DB, 0, NCB, NBUF>(name, dA, dF, ntile, M, wg_per_cu, n_cu, dO, oints, 0, &pl);
 	std::vector<int> hO(oints);
 	CK(hipMemcpy(hO.data(), dO, oints * 4, hipMemcpyDeviceToHost));
 	long long bad = 0;
 	for (size_t v = 0; v < M; v++) {
 		const int vtile = (int)(v / (16 * (size_t)pl.fpw)), within = (int)(v % (16 * (size_t)pl.fpw));
-		const int wid = within / (16 * NAF), f = (within / 16) % NAF, row = within % 16, kg = row / 4, reg = row % 4;
+		const int vg = within / (16 * NAF), f = (within / 16) % NAF, row = within % 16, kg = row / 4, reg = row % 4;
 		for (int c = 0; c < NCOL; c++) {
 			long long ref = 0;
 			for (size_t s = 0; s < (size_t)ntile * 256; s++) {
@@ -147,7 +149,7 @@ static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu)
 				int first, count;
 				s3_items_of(pl, vtile, g, first, count);
 				for (int id = first; id < first + count; id++)
-					got += hO[(((size_t)id * WAVES + wid) * NAF + f) * NBF * 256 + (size_t)(c / 16) * 256 + reg * 64 + kg * 16 + (c % 16)];
+					got += hO[(((size_t)id * WAVES + (vg * NCB + (c / 16) / NBW)) * NAF + f) * NBW * 256 + (size_t)((c / 16) % NBW) * 256 + reg * 64 + kg * 16 + (c % 16)];
 			}
 			if (got != ref) { if (bad < 5) fprintf(stderr, "%s: variant %zu col %d: got %lld want %lld\n", name, v, c, got, ref); bad++; }
 		}
@@ -170,12 +172,27 @@ int main(int argc, char **argv)
 		bad += check<4, 6, 4, 3, 1, 4, 1>("k3 naf6 4+3+1", 4100, 1000, 1, 16);
 		bad += check<4, 4, 4, 1, 1, 1, 1>("k3 naf4 d1", 1000, 130, 1, 8);
 		bad += check<4, 4, 8, 2, 2, 2, 2>("k3 naf4 tiny N", 100, 50, 1, 8);
-		bad += check<4, 2, 12, 3, 1, 4, 2>("k3 naf2 12 waves", 9000, 2100, 1, 8);
+		bad += check<4, 2, 12, 3, 1, 3, 2>("k3 naf2 12 waves", 9000, 2100, 1, 8);
 		bad += check<11, 4, 4, 3, 1, 3, 1>("k13 naf4 4+3+1", 2500, 800, 1, 8);
 		bad += check<6, 3, 8, 3, 1, 3, 1>("k5 naf3", 2100, 900, 1, 8);
 		bad += check<2, 4, 8, 3, 1, 3, 2>("quant naf4", 2100, 900, 1, 8);
 		bad += check<13, 3, 4, 2, 2, 3, 1>("k16 naf3 4+2+2", 1500, 500, 1, 8);
 		bad += check<8, 4, 4, 3, 1, 3, 1>("k8 naf4 4+3+1", 1500, 500, 1, 8);
+		bad += check<12, 3, 4, 2, 2, 3, 1>("k13 nbf12 naf3 4+2+2", 1500, 500, 1, 8);
+		bad += check<12, 6, 4, 2, 2, 3, 1, 2>("k13 nbf12 naf6 2x2", 1500, 700, 1, 8);
+		bad += check<11, 6, 4, 2, 2, 3, 1, 2>("k13 nbf11 naf6 2x2 (6 + 5)", 2100, 700, 1, 8);
+		bad += check<12, 5, 4, 2, 2, 3, 1, 2>("k13 nbf12 naf5 2x2", 1500, 700, 1, 8);
+		bad += check<8, 6, 4, 2, 2, 3, 1, 2>("k8 naf6 2x2", 1500, 700, 1, 8);
+		bad += check<6, 6, 8, 3, 1, 3, 1, 2>("k5 naf6 4x2", 2100, 900, 1, 8);
+		bad += check<16, 4, 4, 2, 2, 3, 1, 2>("k16 nbf16 naf4 2x2", 1100, 300, 1, 8);
+		bad += check<12, 6, 4, 2, 2, 3, 1, 2, 4>("k13 nbf12 naf6 2x2 4 buffers", 1500, 700, 1, 8);
+		bad += check<12, 3, 8, 2, 2, 3, 1, 2>("k13 nbf12 naf3 8 consumers 4x2", 1500, 900, 1, 8);
+		bad += check<13, 3, 8, 2, 2, 3, 1, 2>("k16 nbf13 naf3 8 consumers 4x2", 1100, 900, 1, 8);
+		bad += check<8, 4, 8, 2, 2, 2, 1, 2>("k8 nbf8 naf4 8 consumers 4x2", 1500, 900, 1, 8);
+		bad += check<12, 3, 4, 2, 2, 3, 1, 1, 4>("k13 nbf12 naf3 4 buffers", 1500, 500, 1, 8);
+		bad += check<11, 4, 4, 2, 2, 3, 1, 1, 3>("k13 nbf11 naf4 3 buffers", 1500, 500, 1, 8);
+		bad += check<13, 3, 4, 2, 2, 3, 1, 1, 5>("k16 nbf13 naf3 5 buffers", 1500, 500, 1, 8);
+		bad += check<6, 3, 8, 3, 1, 3, 1, 1, 3>("k5 nbf6 naf3 3 buffers", 2100, 900, 1, 8);
 		return bad ? 1 : 0;
 	}
 	const int N = argc > 1 ? atoi(argv[1]) : 430000;
@@ -187,7 +204,7 @@ int main(int argc, char **argv)
 	CK(hipMalloc((void **)&A, abytes));
 	fill_codes<<<4096, 256>>>((uint32_t *)A, abytes / 4, 12345);
 	if (getenv("ZERO_A")) CK(hipMemset(A, 0, abytes));
-	const int NBFMAX = 13;
+	const int NBFMAX = 16;
 	const size_t flb = (size_t)ntile * 16 * 16 * NBFMAX * 16;
 	CK(hipMalloc((void **)&Fl, flb));
 	{ std::vector<uint8_t> hf(flb); uint64_t x = 5; for (auto &v : hf) v = getenv("ZERO_B") ? 0 : (uint8_t)sm64(x); CK(hipMemcpy(Fl, hf.data(), flb, hipMemcpyHostToDevice)); }
@@ -195,10 +212,78 @@ int main(int argc, char **argv)
 	CK(hipMalloc((void **)&out, oints * 4));
 	CK(hipDeviceSynchronize());
 	printf("N=%d M=%zu ntile=%d rows %.3f GB, %d CUs\n", N, M, ntile, (double)M * ntile * 64 / 1e9, n_cu);
-#define R(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, name) do { \
-	const size_t lds_ = ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * NC * NAF) * 1024; \
+#define R3(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, NCB, NBUF, name) do { \
+	const size_t lds_ = ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * (NC / NCB) * NAF) * 1024; \
 	if (lds_ > 163840) { printf("%-40s skipped: %zu B of LDS\n", name, lds_); break; } \
-	run<NBF, NAF, NC, NLA, NLB, DA, DB, ABL>(name, A, Fl, ntile, M, 1, n_cu, out, oints, reps); } while (0)
+	run<NBF, NAF, NC, NLA, NLB, DA, DB, ABL, NCB, NBUF>(name, A, Fl, ntile, M, 1, n_cu, out, oints, reps); } while (0)
+#define R2(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, NCB, name) R3(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, NCB, 2, name)
+#define R(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, name) R2(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, 1, name)
+	if (getenv("ONLY13")) {
+		R2(12, 6, 4, 2, 2, 3, 1, 0, 2, "k13 nbf12 naf6 2x2");
+		return 0;
+	}
+	if (getenv("W8")) {
+		// eight consumer waves (two per SIMD) as variant groups x column groups
+		R2(12, 6, 4, 2, 2, 3, 1, 16, 2, "k13 nbf12 naf6 4 consumers 2x2");
+		R2(12, 3, 8, 3, 1, 3, 1, 16, 2, "k13 nbf12 naf3 8 consumers 4x2 +3+1");
+		R2(12, 3, 8, 2, 2, 3, 1, 16, 2, "k13 nbf12 naf3 8 consumers 4x2 +2+2");
+		R2(12, 3, 8, 1, 3, 3, 1, 16, 2, "k13 nbf12 naf3 8 consumers 4x2 +1+3");
+		R3(12, 3, 8, 2, 2, 3, 1, 16, 2, 3, "k13 nbf12 naf3 8 consumers 4x2 +2+2, 3 buffers");
+		R2(12, 4, 8, 2, 2, 2, 1, 16, 2, "k13 nbf12 naf4 8 consumers 4x2 +2+2 d2/1");
+		R2(12, 6, 8, 2, 2, 3, 1, 16, 4, "k13 nbf12 naf6 8 consumers 2x4 +2+2");
+		R2(12, 2, 8, 2, 2, 3, 1, 16, 1, "k13 nbf12 naf2 8 consumers 8x1 +2+2");
+		R2(11, 3, 8, 2, 2, 3, 1, 16, 2, "k13 nbf11 naf3 8 consumers 4x2");
+		R2(8, 4, 8, 2, 2, 2, 1, 16, 2, "k8 nbf8 naf4 8 consumers 4x2 d2/1");
+		R2(8, 3, 8, 2, 2, 3, 1, 16, 2, "k8 nbf8 naf3 8 consumers 4x2");
+		R(8, 4, 4, 2, 2, 3, 1, 16, "k8 nbf8 naf4 4+2+2 (one group)");
+		R2(16, 3, 8, 2, 2, 2, 1, 16, 2, "nbf16 naf3 8 consumers 4x2 d2/1");
+		R2(16, 2, 8, 2, 2, 3, 1, 16, 2, "nbf16 naf2 8 consumers 4x2");
+		R2(13, 3, 8, 2, 2, 3, 1, 16, 2, "k16 nbf13 naf3 8 consumers 4x2");
+		return 0;
+	}
+	if (getenv("ABL13")) {
+		R2(12, 6, 4, 2, 2, 3, 1, 16, 2, "full");
+		R2(12, 6, 4, 2, 2, 3, 1, 2 | 16, 2, "no row DMA");
+		R2(12, 6, 4, 2, 2, 3, 1, 4 | 16, 2, "no B DMA");
+		R2(12, 6, 4, 2, 2, 3, 1, 1 | 2 | 4 | 16, 2, "LDS reads + barrier only");
+		R2(12, 6, 4, 2, 2, 3, 1, 1 | 4 | 16, 2, "row DMA + LDS reads, no arithmetic");
+		R2(12, 6, 4, 2, 2, 3, 1, 1 | 2 | 16, 2, "B DMA + LDS reads, no arithmetic");
+		R2(12, 6, 4, 2, 2, 3, 1, 1 | 2 | 8 | 16, 2, "B DMA only (no LDS reads of B, no arithmetic)");
+		R2(12, 6, 4, 2, 2, 3, 1, 1 | 2 | 4 | 8 | 16, 2, "barrier + A reads only");
+		R2(12, 6, 4, 2, 2, 3, 1, 2 | 4 | 8 | 16, 2, "arithmetic only (no DMA, no B reads)");
+		R2(12, 6, 4, 1, 3, 3, 1, 1 | 2 | 8 | 16, 2, "B DMA only, 3 B loaders");
+		R2(12, 6, 4, 1, 1, 3, 1, 1 | 2 | 8 | 16, 2, "B DMA only, 1 B loader");
+		return 0;
+	}
+	if (getenv("ONLY3")) {
+		R(4, 4, 8, 3, 1, 2, 2, 0, "k3 naf4 8+3+1 d2/2");
+		return 0;
+	}
+	if (getenv("WIDE")) {
+		// many covariates: column groups (NCB > 1) and deeper B prefetch (NBUF) against the round-3 forms
+		R(12, 3, 4, 2, 2, 3, 1, 16, "k13 nbf12 naf3 4+2+2 (one group)");
+		R3(12, 3, 4, 2, 2, 3, 1, 16, 1, 3, "k13 nbf12 naf3, 3 buffers");
+		R3(12, 3, 4, 2, 2, 3, 1, 16, 1, 4, "k13 nbf12 naf3, 4 buffers");
+		R3(12, 3, 4, 2, 2, 3, 1, 16, 1, 6, "k13 nbf12 naf3, 6 buffers");
+		R2(12, 6, 4, 2, 2, 3, 1, 16, 2, "k13 nbf12 naf6 2x2");
+		R3(12, 6, 4, 2, 2, 3, 1, 16, 2, 3, "k13 nbf12 naf6 2x2, 3 buffers");
+		R3(12, 6, 4, 2, 2, 3, 1, 16, 2, 4, "k13 nbf12 naf6 2x2, 4 buffers");
+		R3(12, 6, 4, 2, 2, 3, 1, 1 | 16, 2, 4, "k13 nbf12 naf6 2x2, 4 buffers, memory system only");
+		R3(12, 5, 4, 2, 2, 3, 1, 16, 2, 4, "k13 nbf12 naf5 2x2, 4 buffers");
+		R(11, 4, 4, 2, 2, 3, 1, 16, "k13 nbf11 naf4 4+2+2 (one group)");
+		R3(11, 4, 4, 2, 2, 3, 1, 16, 1, 3, "k13 nbf11 naf4, 3 buffers");
+		R(8, 4, 4, 2, 2, 3, 1, 16, "k8 nbf8 naf4 4+2+2 (one group)");
+		R3(8, 4, 4, 2, 2, 3, 1, 16, 1, 3, "k8 nbf8 naf4, 3 buffers");
+		R3(8, 4, 4, 2, 2, 3, 1, 16, 1, 4, "k8 nbf8 naf4, 4 buffers");
+		R(6, 3, 8, 3, 1, 3, 1, 16, "k5 nbf6 naf3 8+3+1 (one group)");
+		R3(6, 3, 8, 3, 1, 3, 1, 16, 1, 3, "k5 nbf6 naf3, 3 buffers");
+		R(13, 3, 4, 2, 2, 3, 1, 16, "k16 nbf13 naf3 (one group)");
+		R3(13, 3, 4, 2, 2, 3, 1, 16, 1, 4, "k16 nbf13 naf3, 4 buffers");
+		R(16, 2, 4, 2, 2, 3, 1, 16, "nbf16 naf2 (one group)");
+		R3(16, 2, 4, 2, 2, 3, 1, 16, 1, 4, "nbf16 naf2, 4 buffers");
+		R3(16, 4, 4, 2, 2, 3, 1, 16, 2, 4, "nbf16 naf4 2x2, 4 buffers");
+		return 0;
+	}
 	// K = 3 (3 value fragments + bit-1)
 	if (getenv("SHORT")) {
 		R(4, 4, 8, 3, 1, 2, 2, 16, "k3 naf4 8+3+1 d2/2");
