@@ -733,8 +733,15 @@ s3_t3_sum_kernel(size_t n, const long long *__restrict__ part, long long *__rest
 // A slab is [consumer wave = (variant group, column group)][f][b < NBW][reg][lane]: NCW waves, NCB column groups
 // of NBW = ceil(NBF / NCB) fragment slots each (the last group's spare slots are never written).
 __global__ void __launch_bounds__(256)
-s3_reduce_kernel(S3Plan pl, int M, int NCW, int NAF, int NBF, int NCB, const int *__restrict__ slabs, int *__restrict__ accbuf, int stride)
+s3_reduce_kernel(S3Plan pl, int M, int NCW, int NAF, int NBF, int NCB, const int *__restrict__ slabs, int *__restrict__ accbuf, int stride,
+	int *__restrict__ counters, int *__restrict__ cursors)
 {
+	// the step's counters and queue cursors start at zero: nothing before the epilogue touches them, and two
+	// memset launches at the head of every step were two more waits for a free CU beside the other lane's kernels
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 32) {
+		if (threadIdx.x < 24) counters[threadIdx.x] = 0;
+		if (threadIdx.x < 8 && cursors) cursors[threadIdx.x] = 0;
+	}
 	const int NBW = (NBF + NCB - 1) / NCB;
 	const int e = blockIdx.x * 256 + threadIdx.x, per = NCW * NAF * NBW * 256, vtile = blockIdx.y;
 	if (e >= per) return;

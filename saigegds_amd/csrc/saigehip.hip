@@ -158,6 +158,9 @@ struct sgx_handle {
 	sgx_stats stats{};
 	bool force_v1 = false;            // SAIGEHIP_SCORE_V1=1: gather kernel instead of the MFMA path
 	bool stats_pending = false;
+	// dense g_pos / g_neg fallback of the last device-resident call, launched by the next sync if that call turned
+	// out to need it (launch_spa, lazy_dense)
+	struct { bool active = false; RowsRef rr{}; size_t M = 0; double *out8 = nullptr; } pend_dense;
 	// Lanes ("lanes" option, 1..SGX_MAX_LANES): device-resident scans go round-robin over this handle and
 	// its twins, each with its own stream and workspace (the model arrays are shared), so that the SPA stage
 	// of one block of variants runs while the score stage of the next one streams the genotypes, and -- where
@@ -638,8 +641,13 @@ static dim3 mf_grid(int n_cu, size_t rows, int ntile, int *tps, int vpb = MF_VPB
 
 // SPA stage of the flagged variants of a call (their records are in h->recs): the series kernels
 // (kern_spa4.h), the per-variant kernels and the exact dense pass.  rr: the call's rows.
+// lazy_dense (device-resident calls, whose results are read after a sync): the exact dense pass -- normally
+// without a single variant -- is not launched here.  An empty launch of its 512-thread workgroups at the end of
+// every step still has to wait for room on a CU beside the other lane's contraction kernel or cumulant pass
+// (0.1-1.2 ms in kernel traces), and with it the lane's completion and its next step.  The next sync of the lane
+// reads the step's counters and launches the pass if a variant asked for it (sync_lane).
 template <int INPUT>
-static int launch_spa(sgx_handle *h, RowsRef rr, size_t M, double *out8)
+static int launch_spa(sgx_handle *h, RowsRef rr, size_t M, double *out8, bool lazy_dense = false)
 {
 	const DevModel &md = h->md;
 	constexpr int PB = 512;
@@ -721,9 +729,10 @@ static int launch_spa(sgx_handle *h, RowsRef rr, size_t M, double *out8)
 					l5, st, rr, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
 					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5, only5, ws5, 4); \
 			}                                                                                \
-			hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rr,    \
-				md, h->recs, h->counters, 2, h->fallback, h->scratch,             \
-				h->scratch_stride, out8);                                                    \
+			if (!lazy_dense)                                                                 \
+				hipLaunchKernelGGL((spa_kernel<KK, PB, INPUT>), sgrid, dim3(PB), 0, st, rr,  \
+					md, h->recs, h->counters, 2, h->fallback, h->scratch,                    \
+					h->scratch_stride, out8);                                                \
 		}                                                                                    \
 		break;
 			FOR_EACH_K(CASE)
@@ -732,7 +741,25 @@ static int launch_spa(sgx_handle *h, RowsRef rr, size_t M, double *out8)
 		}
 		HIPCHK(hipGetLastError());
 		h->stats.spa_launches = (h->force_v1 && INPUT != IN_2BIT) ? 1u : (uint32_t)(4 * ((M + h->vcap4 - 1) / h->vcap4) + 3);
+		if (lazy_dense && !(h->force_v1 && INPUT != IN_2BIT)) { h->pend_dense.active = true; h->pend_dense.rr = rr; h->pend_dense.M = M; h->pend_dense.out8 = out8; }
 	}
+	return SGX_OK;
+}
+
+// the dense pass a lazy call left out, for the variants on its fallback list (counters[2] of that call)
+static int launch_pending_dense(sgx_handle *h)
+{
+	const DevModel &md = h->md;
+	const RowsRef rr = h->pend_dense.rr;
+	double *out8 = h->pend_dense.out8;
+	const dim3 sgrid((unsigned)std::min<size_t>(h->pend_dense.M, (size_t)h->spa_grid));
+	switch (md.K) {
+#define DCASE(KK) case KK: hipLaunchKernelGGL((spa_kernel<KK, 512, IN_2BIT>), sgrid, dim3(512), 0, h->stream, rr, md, h->recs, \
+		h->counters, 2, h->fallback, h->scratch, h->scratch_stride, out8); break;
+		FOR_EACH_K(DCASE)
+#undef DCASE
+	}
+	HIPCHK(hipGetLastError());
 	return SGX_OK;
 }
 
@@ -849,6 +876,14 @@ static int sync_lane(sgx_handle *h)
 	int rc = set_dev(h);
 	if (rc) return rc;
 	HIPCHK(hipStreamSynchronize(h->stream));
+	if (h->pend_dense.active) {
+		h->pend_dense.active = false;
+		if (h->stats_pending && h->h_counters[2] > 0) {
+			rc = launch_pending_dense(h);
+			if (rc) return rc;
+			HIPCHK(hipStreamSynchronize(h->stream));
+		}
+	}
 	if (h->stats_pending) {
 		h->stats.n_spa = (uint64_t)(h->h_counters[0] + h->h_counters[7] - h->h_counters[6] + h->h_counters[5]);   // the tiers (handed-on copies once) + straight to exact
 		h->stats.n_valid = (uint64_t)h->h_counters[1];
@@ -1054,7 +1089,7 @@ static int ensure_buf(sgx_handle *h, T **p, size_t *cap, size_t need)
 
 // Scan of a loaded block on this lane's stream: contraction, sparse pass over the missing genotypes, reduction,
 // epilogue, the FP64 kernel for what the lists do not cover, SPA stage.
-static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double *out8, uint8_t *valid)
+static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double *out8, uint8_t *valid, bool lazy_dense = false)
 {
 	const DevModel &md = h->md;
 	const MfEpi &ep = h->mfe;
@@ -1064,19 +1099,27 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	S3Plan pl{};
 	int NCW = 0, NAFW = 0, NCBW = 1;
 	HIPCHK(hipStreamWaitEvent(st, b->ready, 0));
-	HIPCHK(hipMemsetAsync(h->counters, 0, 24 * sizeof(int), st));
-	if (h->cur5) HIPCHK(hipMemsetAsync(h->cur5, 0, 8 * sizeof(int), st));
-	HIPCHK(hipEventRecord(h->ev[0], st));
+	HIPCHK(hipEventRecord(h->ev[0], st));            // (counters and queue cursors: zeroed by s3_reduce_kernel)
 	int rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)(S3_NR + 1) * M * md.P * 2);      // per-range partials, then the totals
 	if (rc) return rc;
 	rc = ensure_buf(h, &h->s3_ovf, &h->s3_ovf_cap, M);
 	if (rc) return rc;
-	// sums over the missing samples, on the side stream, beside the contraction kernel.  The pass goes FIRST: with
-	// few fragments (3 waves of ~154 registers per SIMD) it finds no room beside a resident contraction workgroup
-	// and would wait for the kernel's end.  From 7 fragments on (2 waves of <= 216 registers) one wave of the pass
-	// fits per SIMD, but launched second and running in the kernel's shadow it slows the kernel by what it saves
-	// (K = 13, same box: 6.13 / 6.20 ms per step first, 6.23 / 6.23 after; SAIGEHIP_T3_ORDER=1 for the experiment).
-	static const int t3_order = [] { const char *e = getenv("SAIGEHIP_T3_ORDER"); return e ? atoi(e) : 0; }();   // 0 first, 1 after
+	// sums over the missing samples, on the side stream.  The pass goes FIRST and the contraction kernel waits for
+	// it (SAIGEHIP_T3_ORDER, experiments: 0 = first without the wait, 1 = after the kernel's launch):
+	//  * with few fragments (3 waves of ~154 registers per SIMD) the pass finds no room beside a resident
+	//    contraction workgroup; launched second it would wait for the kernel's end;
+	//  * from 7 fragments on (2 waves of <= 216 registers) one wave of the pass fits per SIMD, but in the kernel's
+	//    shadow it slows the kernel by what it saves (K = 13, same box: 6.13 / 6.20 ms per step first, 6.23 / 6.23
+	//    after);
+	//  * launched together onto an idle GPU -- with two lanes every other step: this lane's previous step has
+	//    ended, the other lane is in the tail of its SPA stage -- the pass's 25 000 small workgroups and the
+	//    kernel's 256 persistent ones fight for the CUs (a CU holding a wave of the pass per SIMD cannot take a
+	//    contraction workgroup; the workgroups placed late end late, the kernel's work being dealt statically:
+	//    kernel traces show 1.9 ms for the kernel and 1.1 ms for the pass in those steps).  With the wait the pass
+	//    has the GPU for its 0.17 ms (or runs beside the other lane's cumulant pass, where it fits) and the kernel
+	//    starts on free CUs: the same step time (C3 2.36-2.48 ms either way, three same-box pairs), the kernel's
+	//    events 1.07-1.12 ms instead of 1.36-1.42 -- they now time the kernel, not its wait for the pass.
+	static const int t3_order = [] { const char *e = getenv("SAIGEHIP_T3_ORDER"); return e ? atoi(e) : 2; }();
 	const bool t3_after = t3_order == 1;
 	HIPCHK(hipEventRecord(h->s3_fork, st));                  // (the side stream starts where this stream stands NOW)
 	HIPCHK(hipStreamWaitEvent(h->s3_side, h->s3_fork, 0));
@@ -1097,6 +1140,8 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 		return SGX_OK;
 	};
 	if (!t3_after) { rc = launch_t3(); if (rc) return rc; }
+	const bool t3_join_early = t3_order == 2;
+	if (t3_join_early) HIPCHK(hipStreamWaitEvent(st, h->s3_join, 0));
 	static const bool s3_alt = [] { const char *e = getenv("SAIGEHIP_S3_ALT"); return e && e[0] == '1'; }();
 	switch ((s3_alt && NBF == 12) ? 100 + NBF : NBF) {
 #define S3CASE(KEY_, NAF_, NC_, NLA_, NLB_, DA_, DB_, NCB_)                                                  \
@@ -1129,7 +1174,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	{
 		const int per = NCW * NAFW * ((NBF + NCBW - 1) / NCBW) * 256;
 		hipLaunchKernelGGL(s3_reduce_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)pl.vt), dim3(256), 0, st,
-			pl, (int)M, NCW, NAFW, NBF, NCBW, h->s3_slabs, h->mf_acc, ep.acc_stride);
+			pl, (int)M, NCW, NAFW, NBF, NCBW, h->s3_slabs, h->mf_acc, ep.acc_stride, h->counters, h->cur5);
 	}
 	HIPCHK(hipStreamWaitEvent(st, h->s3_join, 0));
 	const int btop = md.quant ? 0 : (int)(2 * M);
@@ -1147,7 +1192,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[1], st));
 	h->stats.score_launches = 6;
-	rc = launch_spa<IN_2BIT>(h, RowsRef{b->tiles, 0, b->ntile, b->cptr, b->cidx, b->corient}, M, out8);
+	rc = launch_spa<IN_2BIT>(h, RowsRef{b->tiles, 0, b->ntile, b->cptr, b->cidx, b->corient}, M, out8, lazy_dense);
 	if (rc) return rc;
 	HIPCHK(hipEventRecord(h->ev[2], st));
 	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 24 * sizeof(int), hipMemcpyDeviceToHost, st));
@@ -1212,7 +1257,7 @@ extern "C" int sgx_scan_block(sgx_handle *h, const sgx_block *b, double *out8_de
 		lane->stats_pending = true;
 		return SGX_OK;
 	}
-	return launch_block_scan(lane, b, b->M, out8_dev, valid_dev);
+	return launch_block_scan(lane, b, b->M, out8_dev, valid_dev, true);
 }
 
 // a scratch block of this lane for calls that bring row-major rows
@@ -1250,7 +1295,7 @@ extern "C" int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev, size_
 	rc = block_put_rows(lane->tmp_blk[0], packed_dev, bpv, 0, M, lane->stream);
 	if (!rc) rc = block_finish(lane->tmp_blk[0], M, lane->stream);
 	if (rc) return rc;
-	return launch_block_scan(lane, lane->tmp_blk[0], M, out8_dev, valid_dev);
+	return launch_block_scan(lane, lane->tmp_blk[0], M, out8_dev, valid_dev, true);
 }
 
 static const size_t STAGE_BYTES = (size_t)1 << 30;    // burden rows are made and scanned in chunks of this size

@@ -389,6 +389,38 @@ def test_two_lanes_give_identical_tables():
     assert_table_close(res[2][0].reshape(-1, 8), res[2][1].reshape(-1), ref, ref_valid, what="lanes=2")
 
 
+def test_dense_pass_of_device_resident_calls_runs_at_the_sync():
+    """sgx_scan_block / sgx_scan_2bit_dev leave the exact dense pass (g_pos / g_neg over all N: normally without a
+    single variant) to the lane's next sync, which reads the step's counters and launches it if a variant asked
+    for it.  With every flagged variant forced onto that pass, the device-resident calls -- one lane and two, the
+    lanes reused before any explicit sync -- must give the host call's rows."""
+    import torch
+    sm, packed = _synthetic_case(3001, 2400, "binary", 0.05, seed=37)
+    ref, ref_valid = _oracle(sm).scan_2bit(packed)
+    dev = torch.device("cuda", 0)
+    with _scanner(sm) as sc:
+        sc.set_option("force_dense", 1)
+        host, host_valid = sc.scan_2bit(packed)
+        assert sc.stats()["n_spa_dense"] > 10
+        bpv = sc.row_stride()
+        pk = torch.zeros((4, 600, bpv), dtype=torch.uint8, device=dev)
+        pk[:, :, :packed.shape[1]] = torch.from_numpy(packed.reshape(4, 600, -1)).to(dev)
+        for lanes in (1, 2):
+            sc.set_option("lanes", lanes)
+            out = torch.full((4, 600, 8), -1.0, dtype=torch.float64, device=dev)
+            valid = torch.zeros((4, 600), dtype=torch.uint8, device=dev)
+            sc.stats_total(reset=True)
+            for b in range(4):
+                sc.scan_2bit_dev(pk[b].data_ptr(), bpv, 600, out[b].data_ptr(), valid[b].data_ptr())
+            tot, ncalls = sc.stats_total(reset=True)          # (syncs)
+            assert ncalls == 4 and tot["n_spa_dense"] > 10
+            o, v = out.cpu().numpy().reshape(-1, 8), valid.cpu().numpy().reshape(-1)
+            assert np.array_equal(v, host_valid)
+            assert np.array_equal(np.nan_to_num(o, nan=-7.0), np.nan_to_num(host, nan=-7.0)), f"lanes={lanes}"
+        sc.set_option("lanes", 1)
+    assert_table_close(host, host_valid, ref, ref_valid, what="force_dense, host call")
+
+
 def test_mfma_lane_map_selftest():
     """v_mfma_i32_16x16x64_i8 operand/result lane maps assumed by the score kernel."""
     from saigegds_amd import _lib
