@@ -696,9 +696,10 @@ s3_t3_kernel(int M, int P, const long long *__restrict__ Q, const unsigned *__re
 #pragma unroll
 		for (int k = 0; k < NB; k++) mine[k] = (e + k * PP + c < e1) ? idx[e + k * PP + c] : 0xFFFFFFFFu;
 		constexpr int UN = PP <= 16 ? 8 : 4;           // gathers issued back to back (PP is a multiple of 8)
+		constexpr int UNR = PP <= 16 ? 2 : 1;
 #pragma unroll
 		for (int k = 0; k < NB; k++)
-#pragma unroll(PP <= 16 ? 2 : 1)
+#pragma unroll UNR
 			for (int j0 = 0; j0 < PP; j0 += UN) {
 				long long q[UN];
 #pragma unroll
