@@ -66,7 +66,17 @@ __host__ __device__ constexpr int spa4_waves(int K) { return K <= 8 ? SPA4_WAVES
 // T_n = y^n c_n(mu)/n! for n = 3..NC added to acc[n - 3];  y = adj * ts.
 // The polynomials in u are summed over explicit powers of u (one multiply-add per coefficient with
 // the coefficient as the constant operand), not by Horner's rule, whose running value would need a
-// register copy of every coefficient first.
+// register copy of every coefficient first.  The first step, C1 u + C0, is written as the three-address
+// v_fma_f64 (C1 in scalar registers, C0 in vector registers, both loop-invariant): left to itself the compiler
+// copies C0 into the result register and adds C1 u with the two-address form -- one v_mov_b64 per polynomial,
+// ten of the ~85 vector instructions a carrier costs at twelve cumulants.
+__device__ __forceinline__ double spa4_fma_svv(double a_sgpr, double x, double c_vgpr)
+{
+	double r;
+	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "s"(a_sgpr), "v"(x), "v"(c_vgpr));
+	return r;
+}
+
 template <int NC>
 __device__ __forceinline__ void spa4_cum_terms(double y, double u, double d, double *acc)
 {
@@ -81,9 +91,13 @@ __device__ __forceinline__ void spa4_cum_terms(double y, double u, double d, dou
 #pragma unroll
 	for (int n = 3; n <= NC; n++) {
 		const int deg = (n - 2) / 2;      // degree of the polynomial in u
-		double b = SPA4_CUM[n][0];
+		double b;
+		if (deg == 0) b = SPA4_CUM[n][0];
+		else {
+			b = spa4_fma_svv(SPA4_CUM[n][1], u, SPA4_CUM[n][0]);
 #pragma unroll
-		for (int k = 1; k <= deg; k++) b = fma(SPA4_CUM[n][k], up[k], b);
+			for (int k = 2; k <= deg; k++) b = fma(SPA4_CUM[n][k], up[k], b);
+		}
 		if (n & 1) {
 			acc[n - 3] = fma(po, b, acc[n - 3]);
 			po *= y2;
