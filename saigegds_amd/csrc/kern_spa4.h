@@ -77,6 +77,13 @@ __device__ __forceinline__ double spa4_fma_svv(double a_sgpr, double x, double c
 	return r;
 }
 
+// g = max(g, |a|) in one instruction (fmax on a loop-carried value costs a second one: the compiler cannot see that
+// it is canonical and quiets it first)
+__device__ __forceinline__ void spa4_max_abs(double &g, double a)
+{
+	asm("v_max_f64 %0, %0, |%1|" : "+v"(g) : "v"(a));
+}
+
 template <int NC>
 __device__ __forceinline__ void spa4_cum_terms(double y, double u, double d, double *acc)
 {
@@ -327,10 +334,10 @@ spa4_moments(RowsRef rr, DevModel md, int nseg, int tier, int btop, int v0, int 
 				const double u = mui * (1 - mui);
 				acc[0] = fma(mui, G, acc[0]);
 				acc[1] += bb;
-				if (adj > 0) acc[2] += adj; else acc[3] += adj;
+				acc[2] += fmax(adj, 0.0); acc[3] += fmin(adj, 0.0);      // (two selects of a 64-bit pair each way cost seven instructions)
 				acc[4] = fma(adj, mui, acc[4]);
 				acc[5] = fma(adj * adj, u, acc[5]);
-				gmax = fmax(gmax, fabs(adj));
+				spa4_max_abs(gmax, adj);
 				if (!(abl & 1)) spa4_cum_terms<NC>(adj * ts, u, 1 - 2 * mui, &acc[6]);
 			};
 			// A lane owns 64 samples, so the lanes' carrier counts differ (binomial): walking them in lock
@@ -494,10 +501,10 @@ spa4_moments_ds(const void *__restrict__ rows, size_t row_bytes, DevModel md, in
 					const double u = mui * (1 - mui);
 					acc[0] = fma(mui, G, acc[0]);
 					acc[1] += bb;
-					if (adj > 0) acc[2] += adj; else acc[3] += adj;
+					acc[2] += fmax(adj, 0.0); acc[3] += fmin(adj, 0.0);      // (two selects of a 64-bit pair each way cost seven instructions)
 					acc[4] = fma(adj, mui, acc[4]);
 					acc[5] = fma(adj * adj, u, acc[5]);
-					gmax = fmax(gmax, fabs(adj));
+					spa4_max_abs(gmax, adj);
 					spa4_cum_terms<NC>(adj * ts, u, 1 - 2 * mui, &acc[6]);
 				}
 			}
