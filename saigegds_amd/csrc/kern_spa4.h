@@ -338,7 +338,12 @@ spa4_moments(RowsRef rr, DevModel md, int nseg, int tier, int btop, int v0, int 
 				acc[4] = fma(adj, mui, acc[4]);
 				acc[5] = fma(adj * adj, u, acc[5]);
 				spa4_max_abs(gmax, adj);
-				if (!(abl & 1)) spa4_cum_terms<NC>(adj * ts, u, 1 - 2 * mui, &acc[6]);
+				// (ablation bit 1, "no cumulant terms", is a build option: tested at run time it is a scalar branch
+				// per carrier that cuts the carrier's arithmetic into three scheduling regions)
+#ifdef SPA4_ABLATE_TERMS
+				if (!(abl & 1))
+#endif
+				spa4_cum_terms<NC>(adj * ts, u, 1 - 2 * mui, &acc[6]);
 			};
 			// A lane owns 64 samples, so the lanes' carrier counts differ (binomial): walking them in lock
 			// step to the largest count would leave ~40 % of the lane-steps empty.  Instead: T =
