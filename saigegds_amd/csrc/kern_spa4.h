@@ -819,13 +819,21 @@ __device__ __forceinline__ bool spa5_series(const double2 *__restrict__ glist, i
 // MODE 1: the exact sweeps (over that list).
 // BLOCK: 512 threads per variant, or 128 where the packed row is short enough for four workgroups per CU
 // (small N: the kernel is bound by the number of variants in flight, not by the work in one).
+// Registers: the 512-thread form is two waves per SIMD at up to 256 registers -- one workgroup per CU then holds
+// the CU's whole register file while it waits on its ~10 dependent phases.  Capped at 128 (SPA5_REG_WAVES 4) half
+// of every register file would stay free for the other lane's small kernels, but the kernel spills and the
+// SPA stage alone goes from 1.26 to 1.65 ms (C3 2.24 -> 2.53-2.57 ms per step): measured, not adopted.
+#ifndef SPA5_REG_WAVES
+#define SPA5_REG_WAVES 2
+#endif
+#define SPA5_WAVES_PER_SIMD(BLOCK) ((BLOCK) == 512 ? SPA5_REG_WAVES : ((BLOCK) / 64 + 3) / 4)
 #ifdef SPA5_PROF   /* phase times of spa5_kernel in 10-ns ticks -> counters[8 + 8 MODE + phase] (diagnostic build only) */
 #define SPA5_T(ph) do { if (tid == 0) { const long long now_ = wall_clock64(); atomicAdd(&counters[8 + 8 * MODE + (ph)], (int)(now_ - tprev_)); tprev_ = now_; } } while (0)
 #else
 #define SPA5_T(ph) do { } while (0)
 #endif
 template <int K, int INPUT, int MODE, int BLOCK>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, SPA5_WAVES_PER_SIMD(BLOCK))
 spa5_kernel(RowsRef rr, DevModel md, const SpaRec *__restrict__ recs,
 	int *__restrict__ counters, const int *__restrict__ todo, int *__restrict__ todo_next, int *__restrict__ cursor,
 	int *__restrict__ fb_dense, uint8_t *__restrict__ scratch, double *__restrict__ out8, int force_dense, int force_exact,
