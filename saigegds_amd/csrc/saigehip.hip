@@ -116,6 +116,7 @@ struct sgx_handle {
 	bool spa5_attr_set[3] = {false, false, false};
 	bool mom_attr_set[3] = {false, false, false};   // per input type: the moments kernels' dynamic LDS size has been raised
 	uint8_t *scr5 = nullptr; int *cur5 = nullptr; int nwg5 = 0;   // spa5_kernel: per-workgroup lists, queue cursor
+	bool spa5_small0 = false;
 	int spa_abl = 0;                  // timing experiments (wrong results)
 	bool force_exact = false;         // test hook: every SPA variant takes the exact exp/log kernels
 	// exact-integer MFMA score path (kern_score_mfma.h)
@@ -310,7 +311,8 @@ static int alloc_workspace(sgx_handle *h)
 	if (!h->md.quant) {
 		// workgroups of the per-variant kernels, each with its scratch lists: 4 per CU where a packed row is
 		// short (128-thread workgroups, see the launch), else one
-		h->nwg5 = (size_t)((N + 63) / 64) * 16 <= 32 * 1024 ? h->n_cu * 4 : h->n_cu;
+		h->spa5_small0 = [] { const char *e = getenv("SAIGEHIP_SPA5_SMALL0"); return e && e[0] == '1'; }();   // (experiment, launch_spa)
+		h->nwg5 = ((size_t)((N + 63) / 64) * 16 <= 32 * 1024 || h->spa5_small0) ? h->n_cu * 4 : h->n_cu;
 		HIPCHK(hipMalloc((void **)&h->scr5, (size_t)h->nwg5 * spa5_wg_bytes(N)));
 		HIPCHK(hipMalloc((void **)&h->cur5, 8 * sizeof(int)));   // [0], [1] spa5_kernel queues; [2], [3] spa4_moments' item queue; [4], [5] spa5_kernel on the blocks' lists
 	}
@@ -722,6 +724,14 @@ static int launch_spa(sgx_handle *h, RowsRef rr, size_t M, double *out8, bool la
 					l5, st, rr, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
 					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5, only5, ws5, 4); \
 			} else {                                                                         \
+				/* (experiment SAIGEHIP_SPA5_SMALL0=1: the series kernel of a block scan in the 128-thread form, four \
+				   workgroups per CU, no row staged -- a variant without a list reads its row from global memory) */ \
+				constexpr int IN5 = INPUT == IN_2BIT ? INPUT : IN_2BIT;                      \
+				if (h->spa5_small0 && INPUT == IN_2BIT && rr.cptr != nullptr && !only5)      \
+				hipLaunchKernelGGL((spa5_kernel<KK, IN5, 0, 128>), dim3((unsigned)h->nwg5), dim3(128), \
+					0, st, rr, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
+					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, (size_t)0, only5, ws5, 3); \
+				else                                                                         \
 				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 0, 512>), dim3((unsigned)h->n_cu), dim3(512), \
 					l5, st, rr, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
 					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5, only5, ws5, 3); \
@@ -856,7 +866,7 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 			t->dF = h->dF; t->dX = h->dX; t->dy = h->dy; t->dmu = h->dmu; t->dmu2 = h->dmu2; t->dXM = h->dXM; t->dFl = h->dFl; t->dQ = h->dQ;
 			t->shares_model = true; t->owner = h;
 			t->force_dense = h->force_dense; t->force_v1 = h->force_v1; t->force_exact = h->force_exact;
-			t->spa_abl = h->spa_abl;
+			t->spa_abl = h->spa_abl; t->spa5_small0 = h->spa5_small0;
 			rc = set_dev(t);
 			if (!rc) rc = alloc_workspace(t);
 			if (rc) { sgx_free(t); return rc; }
