@@ -744,7 +744,9 @@ s3_reduce_kernel(S3Plan pl, int M, int NCW, int NAF, int NBF, int NCB, const int
 		if (threadIdx.x < 8 && cursors) cursors[threadIdx.x] = 0;
 	}
 	const int NBW = (NBF + NCB - 1) / NCB;
-	const int e = blockIdx.x * 256 + threadIdx.x, per = NCW * NAF * NBW * 256, vtile = blockIdx.y;
+	// a thread takes four consecutive slab elements: the same (fragment, register, variant), four columns -- one
+	// 16-byte load per item and one 16-byte store (a quarter of the load instructions of the one-element form)
+	const int e = (blockIdx.x * 256 + threadIdx.x) * 4, per = NCW * NAF * NBW * 256, vtile = blockIdx.y;
 	if (e >= per) return;
 	const int lane = e & 63, reg = (e >> 6) & 3, fb = e >> 8;           // fb = (wave NAF + f) NBW + b
 	const int bw = fb % NBW, wf = fb / NBW;                             // wf = wave NAF + f
@@ -753,13 +755,13 @@ s3_reduce_kernel(S3Plan pl, int M, int NCW, int NAF, int NBF, int NCB, const int
 	if (b >= NBF) return;
 	const int v = (vtile * pl.fpw + (wave / NCB) * NAF + f) * 16 + (lane >> 4) * 4 + reg;
 	if (v >= M) return;
-	int sum = 0;
+	s3_v4i sum = (s3_v4i){0, 0, 0, 0};
 	for (int g = 0; g < pl.ng; g++) {
 		int first, count;
 		s3_items_of(pl, vtile, g, first, count);
-		for (int id = first; id < first + count; id++) sum += slabs[(size_t)id * per + e];
+		for (int id = first; id < first + count; id++) sum += *reinterpret_cast<const s3_v4i *>(slabs + (size_t)id * per + e);
 	}
-	accbuf[(size_t)v * stride + b * 16 + (lane & 15)] = sum;
+	*reinterpret_cast<s3_v4i *>(accbuf + (size_t)v * stride + b * 16 + (lane & 15)) = sum;      // (stride is a multiple of 16 ints)
 }
 
 // ---- epilogue: one thread per variant.  As score_mfma_epilogue, with the missing-sample sums from the T3 pass

@@ -1183,7 +1183,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	if (t3_after) { rc = launch_t3(); if (rc) return rc; }
 	{
 		const int per = NCW * NAFW * ((NBF + NCBW - 1) / NCBW) * 256;
-		hipLaunchKernelGGL(s3_reduce_kernel, dim3((unsigned)((per + 255) / 256), (unsigned)pl.vt), dim3(256), 0, st,
+		hipLaunchKernelGGL(s3_reduce_kernel, dim3((unsigned)((per / 4 + 255) / 256), (unsigned)pl.vt), dim3(256), 0, st,
 			pl, (int)M, NCW, NAFW, NBF, NCBW, h->s3_slabs, h->mf_acc, ep.acc_stride, h->counters, h->cur5);
 	}
 	HIPCHK(hipStreamWaitEvent(st, h->s3_join, 0));
