@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("SAIGEHIP_LIB") or os.path.join(_HERE, "libsaigehip.so
 EXPORTS = (
     "sgx_version", "sgx_last_error", "sgx_device_count", "sgx_init", "sgx_free",
     "sgx_set_thresholds", "sgx_score_layout", "sgx_scan_2bit", "sgx_scan_2bit_dev", "sgx_scan_u8", "sgx_scan_i32", "sgx_scan_f64", "sgx_host_alloc", "sgx_host_free", "sgx_burden_2bit", "sgx_geno_stats_2bit", "sgx_decode_dbit2",
-    "sgx_block_bytes", "sgx_block_create", "sgx_block_free", "sgx_block_load_dev", "sgx_block_load", "sgx_block_variants", "sgx_scan_block",
+    "sgx_block_bytes", "sgx_block_create", "sgx_block_create_ex", "sgx_block_free", "sgx_block_load_dev", "sgx_block_load", "sgx_block_variants", "sgx_scan_block",
     "sgx_sync", "sgx_get_stats", "sgx_get_stats_total", "sgx_row_stride", "sgx_synth_2bit_dev", "sgx_selftest", "sgx_set_option",
     "sgx_grm_init", "sgx_grm_init_dev", "sgx_grm_crossprod_dev", "sgx_grm_sync", "sgx_grm_free", "sgx_grm_diag", "sgx_grm_crossprod", "sgx_grm_pcg",
 )
@@ -106,6 +106,8 @@ def load():
     L.sgx_block_bytes.argtypes = [C.c_int32, sz]
     L.sgx_block_create.restype = C.c_int
     L.sgx_block_create.argtypes = [C.c_int32, sz, C.c_int, C.POINTER(vp)]
+    L.sgx_block_create_ex.restype = C.c_int
+    L.sgx_block_create_ex.argtypes = [C.c_int32, sz, C.c_int, C.c_longlong, C.POINTER(vp)]
     L.sgx_block_free.restype = None
     L.sgx_block_free.argtypes = [vp]
     L.sgx_block_load_dev.restype = C.c_int
@@ -276,7 +278,7 @@ class Scanner:
     def scan_2bit_dev(self, packed_ptr: int, bpv: int, m: int, out_ptr: int, valid_ptr: int):
         check(self._L.sgx_scan_2bit_dev(self._h, packed_ptr, bpv, m, out_ptr, valid_ptr))
 
-    # -- genotype blocks (the library's tiled device layout; Block below) ---
+    # -- genotype blocks (rows + their sparse side resident on the device; Block below) ---
     def load_block_dev(self, block: "Block", packed_ptr: int, bpv: int, m: int):
         """Rows already in this GPU's memory -> block (asynchronous on the handle's stream)."""
         check(self._L.sgx_block_load_dev(self._h, block._b, packed_ptr, bpv, m))
@@ -327,13 +329,18 @@ class Scanner:
 
 
 class Block:
-    """A block of variants in the library's device layout (``sgx_block``): depends on the number of
-    samples only, so one loaded block can be scanned with any number of models."""
+    """A block of variants resident on the device (``sgx_block``: the 2-bit rows, the positions of their missing
+    genotypes, the carrier lists of the rare variants): depends on the number of samples only, so one loaded
+    block can be scanned with any number of models.  ``clist_avg`` (test hook): room of the carrier lists in
+    entries per variant."""
 
-    def __init__(self, n_samp: int, max_variants: int, device: int = 0):
+    def __init__(self, n_samp: int, max_variants: int, device: int = 0, clist_avg: int = None):
         self._L = load()
         b = C.c_void_p()
-        check(self._L.sgx_block_create(int(n_samp), int(max_variants), int(device), C.byref(b)))
+        if clist_avg is None:
+            check(self._L.sgx_block_create(int(n_samp), int(max_variants), int(device), C.byref(b)))
+        else:
+            check(self._L.sgx_block_create_ex(int(n_samp), int(max_variants), int(device), int(clist_avg), C.byref(b)))
         self._b = b
         self.n, self.cap = int(n_samp), int(max_variants)
 

@@ -86,7 +86,19 @@ __device__ __forceinline__ void s3_unpack_op(uint32_t w, uint32_t &w4, s3_v4i &v
 // LDS per workgroup: (DB + 1) x 4 NBF + (DA + 1) x NC NAF KiB.
 // ABL (timing tool only, wrong results): 1 no unpack/MFMA, 2 no row DMA, 4 no B DMA, 8 no LDS reads of B,
 //   16 clock stamps (s_memtime / s_memrealtime per workgroup behind the slabs)
-template <int NBF, int NAF, int NC, int NLA, int NLB, int DA, int DB, int ABL = 0, int NCB = 1, int NBUF_ = 2>
+// RM = 1: the rows are the caller's ROW-MAJOR 2-bit rows (pl.bpv bytes each, pl.nrow of them), not tiles.  A tile of
+//   a row is 64 B -- half a cache line -- and 16 half lines of 16 rows per wave instruction read 15-20 % slower than
+//   a tile's contiguous KiB, whole lines of 8 rows at the tiles' rate (measured: tools/README.md, round 4).  So the
+//   row ring holds PAIRS of tiles (DA pairs ahead, DA + 1 slots of 2 NPA KiB): a row loader's DMA instruction
+//   fetches the 128-byte line (tiles t, t + 1) of rows 8 h .. 8 h + 7 of a fragment into KiB 2 p + h of the slot,
+//   lanes 8 i .. 8 i + 7 = the eight 16-byte pieces of row 8 h + i, in the order c = j ^ sigma(i, h),
+//   sigma = (i >> 1) | (h << 2), c = 4 (tile parity) + kg: with that order the consumers' ds_read_b128 lane groups
+//   (16 lanes = the 64-sample pieces of 16 rows at one kg) touch every bank once.  The consumers' only change is
+//   the address of a row piece (per tile parity).  B tiles and the barrier stay per tile.  (Staging the lines
+//   through the loaders' registers and ds_write_b128 into a single-tile ring was built first: same memory rate,
+//   but the LDS store path -- ~80 B per clock and CU -- cost 0.18 ms of a 1.07-ms kernel.)
+//   (RM = 2: timing experiment of the tool, wrong results.)
+template <int NBF, int NAF, int NC, int NLA, int NLB, int DA, int DB, int ABL = 0, int NCB = 1, int NBUF_ = 2, int RM = 0>
 __global__ void __launch_bounds__(64 * (NC + NLA + NLB), (NC + NLA + NLB + 3) / 4)
 score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3Plan pl, int *__restrict__ out, unsigned long long *__restrict__ stamps)
 {
@@ -98,8 +110,8 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 	constexpr int TILE_BYTES = 16 * NCOL * 16;
 	constexpr int NPB = TILE_BYTES / 1024;                    // KiB pieces of a B tile = 4 NBF
 	constexpr int NPA = NCV * NAF;                            // KiB pieces of a tile's rows
-	constexpr int RA = DA + 1, RB = DB + 1;                   // ring slots
-	constexpr int SLOT_A = NPA * 1024;
+	constexpr int RA = DA + 1, RB = DB + 1;                   // ring slots (RM = 1: the row ring's slots are PAIRS of tiles)
+	constexpr int SLOT_A = (RM == 1 ? 2 : 1) * NPA * 1024;
 	static_assert(DA >= 1 && DB >= 1, "at least one tile ahead");
 	extern __shared__ __attribute__((aligned(16))) uint8_t s3_smem[];   // RB x TILE_BYTES (B), then RA x SLOT_A (rows)
 
@@ -107,7 +119,8 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 	const int x = blockIdx.x & 7, y = blockIdx.x >> 3;
 	const int g = x % pl.ng, i = y * (8 / pl.ng) + x / pl.ng;
 	const int nk = pl.rf + (i < pl.rem * pl.f ? 1 : 0);     // items of this workgroup
-	const int T0 = (int)((long long)g * pl.ntile / pl.ng), T1 = (int)((long long)(g + 1) * pl.ntile / pl.ng);
+	// tile ranges in whole PAIRS of tiles (ntile is even): a pair of tiles is one 128-byte line of a row-major row
+	const int T0 = 2 * (int)((long long)g * (pl.ntile / 2) / pl.ng), T1 = 2 * (int)((long long)(g + 1) * (pl.ntile / 2) / pl.ng);
 	unsigned long long st0 = 0, sr0 = 0;
 	if (ABL & 16) { st0 = __builtin_amdgcn_s_memtime(); sr0 = __builtin_amdgcn_s_memrealtime(); }
 
@@ -119,7 +132,7 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 		else {
 			const int q = i % pl.f, vv = i / pl.f, len = T1 - T0;
 			p.vtile = pl.rf * pl.wpg + vv;
-			p.t = T0 + q * len / pl.f; p.t1 = T0 + (q + 1) * len / pl.f;
+			p.t = T0 + 2 * (q * (len / 2) / pl.f); p.t1 = T0 + 2 * ((q + 1) * (len / 2) / pl.f);
 			p.id = g * pl.ipg + pl.rf * pl.wpg + i;
 		}
 	};
@@ -132,22 +145,86 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 		const bool rows = wid < NC + NLA;
 		const int l = __builtin_amdgcn_readfirstlane(rows ? wid - NC : wid - NC - NLA);
 		const int voff = (rows ? s3_dma_lane(lane) : lane) * 16;   // rows: LDS slot `lane` receives the KiB's slot of (variant r, piece kg)
+		// row-major rows: LDS slot `lane` receives 16 B of row (lane & 15), piece (lane >> 4); in the block's last
+		// fragment the rows past the end are the last row again (their sums are never read)
+		const unsigned rm_bpv = (unsigned)pl.bpv;
 		Pos pa = pc;
 		int sl = 0;                                           // slot of the next tile to issue
 		int ahead = 0;                                        // tiles issued beyond the one the next barrier releases
-		if (rows) {
+		if (rows && RM == 1) {
+			// ---- row-major rows: pairs of tiles, two DMA instructions (rows 0-7, rows 8-15) per fragment and pair
+			constexpr int PLO = NPA / NLA, NHI = NPA % NLA;       // loaders l < NHI take PLO + 1 fragments
+			static_assert(2 * (PLO + 1) * (DA > 1 ? DA - 1 : 1) < 64, "vmcnt range");
+			// lane = 8 i + j: row 8 h + i of the fragment, piece c = j ^ sigma(i, h) of its line
+			const int li = lane >> 3, lj = lane & 7;
+			const int rlast = pl.nrow - 1 - 16 * (pl.nfrag - 1);       // last row of the block's last fragment
+			unsigned vo[2], vol[2];                                    // per-lane byte offsets (h = 0, 1); in the last fragment
+#pragma unroll
+			for (int h = 0; h < 2; h++) {
+				const unsigned c = (unsigned)(lj ^ ((li >> 1) | (h << 2)));
+				vo[h] = (unsigned)(8 * h + li) * rm_bpv + c * 16u;
+				vol[h] = (unsigned)min(8 * h + li, rlast) * rm_bpv + c * 16u;
+			}
+			auto issue = [&]() {
+				const size_t f0 = (size_t)pa.vtile * pl.fpw;
+				const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(A + f0 * 16 * (size_t)pl.bpv), 0, 0xFFFFFFFFu, 0x00020000);
+				const int lastf = pl.nfrag - 1 - (int)f0;      // past the end: the last fragment again (never stored)
+#pragma unroll
+				for (int j = 0; j <= PLO; j++) {
+					const int p = l + j * NLA;
+					if (p >= NPA || (ABL & 2)) break;
+					const int pp = min(p, lastf);
+					// (fpw fragments x 16 rows x bpv bytes: far below 4 GiB)
+					const int so = (int)((unsigned)pp * 16u * rm_bpv + (unsigned)(pa.t >> 1) * 128u);
+#pragma unroll
+					for (int h = 0; h < 2; h++)
+						__builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(s3_smem + RB * TILE_BYTES + sl * SLOT_A + (2 * p + h) * 1024),
+							16, (int)(pp == lastf ? vol[h] : vo[h]), so, 0, 0);
+				}
+				sl = sl + 1 == RA ? 0 : sl + 1;
+				pos_next(pa); pos_next(pa);
+			};
+#pragma unroll
+			for (int d = 0; d < DA; d++) if (pa.k < nk) { issue(); ahead++; }
+			int k = 0;                                            // tiles of this workgroup's stream so far
+			while (pc.k < nk) {
+				if (!(k & 1)) {
+					// the pair this barrier opens has landed; `ahead - 1` younger pairs may fly
+					if (ahead == DA && DA > 1) { if (l < NHI) S3_WAITCNT_VM(2 * (PLO + 1) * (DA - 1)); else S3_WAITCNT_VM(2 * PLO * (DA - 1)); }
+					else S3_WAITCNT_VM(0);
+				}
+				__builtin_amdgcn_s_barrier();
+				if (!(k & 1)) {
+					// the consumers have left the pair before this one: its slot takes the pair DA ahead
+					ahead--;
+					if (pa.k < nk) { issue(); ahead++; }
+				}
+				k++;
+				pos_next(pc);
+			}
+		} else if (rows) {
 			constexpr int PLO = NPA / NLA, NHI = NPA % NLA;       // loaders l < NHI take PLO + 1 pieces
 			static_assert((PLO + 1) * (DA - 1) < 64, "vmcnt range");
 			auto issue = [&]() {
 				// rows of the item's variant tile: a descriptor at its first fragment, the fragment and the tile
 				// in the scalar offset (fpw fragments x ntile KiB: far below 4 GiB)
 				const size_t f0 = (size_t)pa.vtile * pl.fpw;
-				const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void *)(A + f0 * pl.ntile * 1024), 0, 0xFFFFFFFFu, 0x00020000);
+				const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+					(void *)(A + (RM ? f0 * 16 * (size_t)pl.bpv : f0 * pl.ntile * 1024)), 0, 0xFFFFFFFFu, 0x00020000);
 				const int lastf = pl.nfrag - 1 - (int)f0;      // past the end: the last fragment again (never stored)
 #pragma unroll
 				for (int j = 0; j <= PLO; j++) {
 					const int p = l + j * NLA;
 					if (p >= NPA || (ABL & 2)) break;
+					if constexpr (RM == 1) {
+						// (not reached: RM = 1 has its own loop below)
+					} else if constexpr (RM == 2) {
+						// (timing experiment, wrong results: the same bytes as whole 128-B lines of 8 rows per instruction)
+						const int pp = min(p, lastf);
+						__builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(s3_smem + RB * TILE_BYTES + sl * SLOT_A + p * 1024),
+							16, (int)((unsigned)(lane >> 3) * rm_bpv + (unsigned)(lane & 7) * 16u),
+							(int)(((unsigned)pp * 16u + (unsigned)(pa.t & 1) * 8u) * rm_bpv + (unsigned)(pa.t >> 1) * 128u), 0, 0);
+					} else
 					__builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(s3_smem + RB * TILE_BYTES + sl * SLOT_A + p * 1024),
 						16, voff, (min(p, lastf) * pl.ntile + pa.t) * 1024, 0, 0);
 				}
@@ -200,6 +277,11 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 	// LDS byte addresses of this lane's 16 B of a row piece and of its B fragment (sample group 4 kg, column r)
 	const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)s3_smem;
 	const uint32_t ring_lds = smem_lds + RB * TILE_BYTES + vg * (NAF * 1024) + lane * 16;
+	// row-major rows (RM = 1): piece (r, kg) of the pair's tile of parity par sits in KiB 2 p + (r >> 3) of the pair's
+	// slot at 16-byte position 8 i + ((4 par + kg) ^ sigma(i, h)), i = r & 7, h = r >> 3 (see the loaders)
+	const int rm_sig = ((r & 7) >> 1) | ((r >> 3) << 2);
+	const uint32_t ring_rm = smem_lds + RB * TILE_BYTES + vg * (NAF * 2048) + (uint32_t)(r >> 3) * 1024u + (uint32_t)(r & 7) * 128u;
+	const uint32_t ring_rm0 = ring_rm + (uint32_t)(kg ^ rm_sig) * 16u, ring_rm1 = ring_rm + (uint32_t)((4 + kg) ^ rm_sig) * 16u;
 
 	// The body of a consumer wave of column group CG: B fragments [B0, B0 + NBW) of the tile against the NAF row
 	// pieces of its variant group.  With NCB > 1 the waves of a variant group read the SAME row pieces and unpack
@@ -245,16 +327,18 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 		static_assert(!HASB1 || NBW >= 2 || NCB == 1, "a column group of the b1 fragment alone has no slot for its unpack");
 
 		int sa = 0, sb = 0;        // ring slots of the current tile (rows, B)
+		int par = 0;               // parity of the tile in the workgroup's stream (every item is whole pairs)
 		while (pc.k < nk) {
 			__builtin_amdgcn_sched_barrier(0);
 			__builtin_amdgcn_s_barrier();
 			__builtin_amdgcn_sched_barrier(0);
 			// (LDS reads by inline asm with counted lgkmcnt waits: behind an LDS-DMA the compiler puts vmcnt(0) in
 			// front of every LDS read it can see)
-			const uint32_t a_addr = ring_lds + (uint32_t)(sa * SLOT_A);
+			const uint32_t a_addr = (RM == 1 ? (par ? ring_rm1 : ring_rm0) : ring_lds) + (uint32_t)(sa * SLOT_A);
+			constexpr int AFS = RM == 1 ? 2048 : 1024;            // bytes between a wave's row pieces
 			const uint32_t b_addr = bt_lds + (uint32_t)(sb * TILE_BYTES);
 			s3_v4i aw[NAF];
-			s3_static_for<0, NAF>([&](auto F) { constexpr int f = decltype(F)::value; S3_DS_READ(aw[f], a_addr, f * 1024); });
+			s3_static_for<0, NAF>([&](auto F) { constexpr int f = decltype(F)::value; S3_DS_READ(aw[f], a_addr, f * AFS); });
 			s3_v4i bf[NBUF][BCH];
 			auto read_chunk = [&](auto CI) {
 				constexpr int ci = decltype(CI)::value, u = ci / NCH, b0 = (ci % NCH) * BCH;
@@ -358,8 +442,9 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 						}
 			}
 			pos_next(pc);
-			sa = sa + 1 == RA ? 0 : sa + 1;
+			if (RM != 1 || par) sa = sa + 1 == RA ? 0 : sa + 1;         // (a pair's slot serves two tiles)
 			sb = sb + 1 == RB ? 0 : sb + 1;
+			par ^= 1;
 		}
 	};
 	if constexpr (NCB == 1) consume(std::integral_constant<int, 0>());
@@ -371,87 +456,21 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 #endif
 }
 
+// Per NBF the product's instantiation of score3_kernel on row-major rows (RM = 1): fragments per consumer wave,
+// consumer / row-loader / B-loader waves, pairs of row tiles ahead, B tiles ahead -- what fits 160 KiB of LDS
+// ((DB + 1) x 4 NBF + (DA + 1) x 2 NC NAF KiB) and the registers of that many waves, the fastest of the forms
+// measured with tools/score3_bench (tools/README.md).
+#define S3_FOR_EACH_NBF(X) \
+	X(2, 4, 8, 3, 1, 1, 2) X(3, 4, 8, 3, 1, 1, 1) X(4, 4, 8, 3, 1, 1, 1) X(5, 3, 8, 3, 1, 1, 2) X(6, 3, 8, 3, 1, 1, 1) \
+	X(7, 4, 4, 2, 2, 2, 1) X(8, 4, 4, 2, 2, 2, 1) X(9, 4, 4, 2, 2, 1, 1) X(10, 4, 4, 2, 2, 1, 1) X(11, 4, 4, 2, 2, 1, 1) \
+	X(12, 3, 4, 2, 2, 1, 1) X(13, 3, 4, 2, 2, 1, 1) X(14, 2, 4, 2, 2, 2, 1) X(15, 2, 4, 2, 2, 1, 1) X(16, 2, 4, 2, 2, 1, 1)
+static inline size_t s3_lds_bytes(int NBF, int NAF, int NC, int DA, int DB) { return ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * 2 * NC * NAF) * 1024; }
+
 #ifndef S3_KERNEL_ONLY   /* tools/score3_bench.hip takes the contraction kernel alone */
 // ===========================================================================================================
-// Genotype blocks: ingest (row-major 2-bit rows -> tiled layout + lists of the missing genotypes), the sparse
-// T3 pass, the reduction of the item slabs and the epilogue.
-
-// ---- ingest 1: transpose to tiles, count the missing codes per (sample range, variant).
-// One wave per fragment of 16 variants; lane (r, kg) moves the 16 B of variant 16 frag + r that cover samples
-// 64 kg .. 64 kg + 63 of the tile.  Codes of samples >= N are cleared (a stray 3 there must not be listed).
-// Also per variant: the number of non-zero codes and of codes 2 (nzv, n2v: what decides whether the variant gets
-// a carrier list, s3_ingest_clist_kernel).
-// rows: M rows of bpv bytes, bpv >= 64 ntile, 16-byte aligned.
-__global__ void __launch_bounds__(256)
-s3_ingest_tile_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int M, int ntile,
-	uint8_t *__restrict__ tiles, int *__restrict__ cnt, size_t cap, int *__restrict__ nzv, int *__restrict__ n2v)
-{
-	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-	const int frag = blockIdx.x * 4 + wid, nfrag = (M + 15) / 16;
-	if (frag >= nfrag) return;
-	const int r = lane & 15, kg = lane >> 4, v = frag * 16 + r;
-	const bool live = v < M;
-	const uint8_t *src = rows + (size_t)(live ? v : 0) * bpv + kg * 16;
-	uint8_t *dst = tiles + (size_t)frag * ntile * 1024 + s3_dma_lane(lane) * 16;
-	constexpr int UN = 4;
-	int rg = 0, tend = s3_range_t0(1, ntile), c = 0, cz = 0, c2 = 0;
-	for (int t0 = 0; t0 < ntile; t0 += UN) {
-		uint4 w[UN];
-#pragma unroll
-		for (int j = 0; j < UN; j++) {
-			w[j] = make_uint4(0u, 0u, 0u, 0u);
-			if (live && t0 + j < ntile) w[j] = *reinterpret_cast<const uint4 *>(src + (size_t)(t0 + j) * 64);
-		}
-#pragma unroll
-		for (int j = 0; j < UN; j++) {
-			const int t = t0 + j;
-			if (t >= ntile) break;
-			while (t >= tend) {         // the range is complete: its count per variant (the four kg lanes together)
-				int tot = c + __shfl_xor(c, 16, 64);
-				tot += __shfl_xor(tot, 32, 64);
-				if (kg == 0 && live) cnt[(size_t)rg * cap + v] = tot;
-				c = 0; rg++; tend = s3_range_t0(rg + 1, ntile);
-			}
-			const int s0 = t * 256 + kg * 64;
-			uint32_t d[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				const int keep = N - s0 - 16 * u;
-				d[u] &= (keep >= 16) ? 0xFFFFFFFFu : ((keep <= 0) ? 0u : ((1u << (2 * keep)) - 1u));
-				c += __popc(d[u] & (d[u] >> 1) & 0x55555555u);
-				cz += __popc((d[u] | (d[u] >> 1)) & 0x55555555u);
-				c2 += __popc(~d[u] & (d[u] >> 1) & 0x55555555u);
-			}
-			*reinterpret_cast<uint4 *>(dst + (size_t)t * 1024) = make_uint4(d[0], d[1], d[2], d[3]);
-		}
-	}
-	while (rg < S3_NR) {
-		int tot = c + __shfl_xor(c, 16, 64);
-		tot += __shfl_xor(tot, 32, 64);
-		if (kg == 0 && live) cnt[(size_t)rg * cap + v] = tot;
-		c = 0; rg++;
-	}
-	cz += __shfl_xor(cz, 16, 64); cz += __shfl_xor(cz, 32, 64);
-	c2 += __shfl_xor(c2, 16, 64); c2 += __shfl_xor(c2, 32, 64);
-	if (kg == 0 && live) { nzv[v] = cz; n2v[v] = c2; }
-}
-
-// ---- ingest 2: per variant n3 and the overflow mark, then the exclusive prefix of the listed counts in
-// (range, variant) order.  A variant whose missing genotypes exceed `lim`, or that no longer fits the block's
-// list, is marked (ovf = 1; its counts are skipped): the scan takes it through the FP64 kernel.
-// Five small launches, every pass coalesced: counts per variant; budget in variant order (one workgroup);
-// sums of 1024-element pieces of the (range, variant) sequence; their prefix (one workgroup); the offsets.
-__global__ void __launch_bounds__(256)
-s3_ingest_count_kernel(int M, size_t cap, int lim, const int *__restrict__ cnt, int *__restrict__ n3, uint8_t *__restrict__ ovf)
-{
-	const int v = blockIdx.x * 256 + threadIdx.x;
-	if (v >= M) return;
-	int t = 0;
-#pragma unroll
-	for (int g = 0; g < S3_NR; g++) t += cnt[(size_t)g * cap + v];
-	n3[v] = t;
-	ovf[v] = t > lim ? 1 : 0;
-}
+// Around the contraction kernel: the offsets of the carrier lists (the lists themselves: kern_lists.h), the sparse
+// T3 pass over the missing genotypes, the reduction of the item slabs and the epilogue.
+#include "kern_lists.h"
 
 // exclusive prefix over the threads of a 1024-thread workgroup (sh: 1024 values)
 __device__ __forceinline__ unsigned long long s3_block_excl(unsigned long long x, unsigned long long *sh)
@@ -468,54 +487,6 @@ __device__ __forceinline__ unsigned long long s3_block_excl(unsigned long long x
 	const unsigned long long incl = sh[tid];
 	__syncthreads();
 	return incl - x;
-}
-
-__global__ void __launch_bounds__(1024)
-s3_ingest_budget_kernel(int M, unsigned idx_cap, const int *__restrict__ n3, uint8_t *__restrict__ ovf)
-{
-	__shared__ unsigned long long sh[1024];
-	const int tid = threadIdx.x, per = (M + 1023) / 1024, v0 = tid * per, v1 = min(M, v0 + per);
-	unsigned long long mine = 0;
-	for (int v = v0; v < v1; v++) if (!ovf[v]) mine += (unsigned long long)n3[v];
-	unsigned long long base = s3_block_excl(mine, sh);
-	for (int v = v0; v < v1; v++) {
-		if (ovf[v]) continue;
-		base += (unsigned long long)n3[v];
-		if (base > (unsigned long long)idx_cap) ovf[v] = 1;     // (and, the sum only growing, every later variant)
-	}
-}
-
-// element e = g M + v of the (range, variant) sequence: its listed count
-__device__ __forceinline__ unsigned s3_listed(size_t e, int M, size_t cap, const int *__restrict__ cnt, const uint8_t *__restrict__ ovf)
-{
-	const size_t g = e / (size_t)M, v = e - g * (size_t)M;
-	return ovf[v] ? 0u : (unsigned)cnt[g * cap + v];
-}
-
-__global__ void __launch_bounds__(256)
-s3_ingest_piece_kernel(int M, size_t cap, const int *__restrict__ cnt, const uint8_t *__restrict__ ovf, unsigned long long *__restrict__ piece)
-{
-	__shared__ unsigned sh[4];
-	const size_t tot = (size_t)S3_NR * M, e0 = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
-	unsigned t = 0;
-#pragma unroll
-	for (int k = 0; k < 4; k++) if (e0 + k < tot) t += s3_listed(e0 + k, M, cap, cnt, ovf);
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
-	if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = t;
-	__syncthreads();
-	if (threadIdx.x == 0) piece[blockIdx.x] = (unsigned long long)sh[0] + sh[1] + sh[2] + sh[3];
-}
-
-__global__ void __launch_bounds__(1024)
-s3_ingest_piece_scan_kernel(int npiece, unsigned long long *__restrict__ piece)
-{
-	__shared__ unsigned long long sh[1024];
-	const int tid = threadIdx.x, per = (npiece + 1023) / 1024, p0 = tid * per, p1 = min(npiece, p0 + per);
-	unsigned long long mine = 0;
-	for (int p = p0; p < p1; p++) mine += piece[p];
-	unsigned long long base = s3_block_excl(mine, sh);
-	for (int p = p0; p < p1; p++) { const unsigned long long x = piece[p]; piece[p] = base; base += x; }
 }
 
 // ---- carrier lists of the rare variants (the input of the per-variant SPA kernels, kern_spa4.h): a variant
@@ -559,136 +530,25 @@ s3_ingest_clist_kernel(int M, unsigned cidx_cap, const int *__restrict__ cn, uns
 	if (tid == 1023) cptr[M] = (unsigned)min(base, (unsigned long long)cidx_cap);
 }
 
-__global__ void __launch_bounds__(256)
-s3_ingest_ptr_kernel(int M, size_t cap, const int *__restrict__ cnt, const uint8_t *__restrict__ ovf,
-	const unsigned long long *__restrict__ piece, unsigned *__restrict__ ptr)
-{
-	__shared__ unsigned sh[4];
-	const size_t tot = (size_t)S3_NR * M, e0 = (size_t)blockIdx.x * 1024 + threadIdx.x * 4;
-	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-	unsigned c[4], t = 0;
-#pragma unroll
-	for (int k = 0; k < 4; k++) { c[k] = e0 + k < tot ? s3_listed(e0 + k, M, cap, cnt, ovf) : 0u; t += c[k]; }
-	unsigned incl = t;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) { const unsigned up = __shfl_up(incl, o, 64); if (lane >= o) incl += up; }
-	if (lane == 63) sh[wid] = incl;
-	__syncthreads();
-	unsigned base = (unsigned)piece[blockIdx.x] + incl - t;
-	for (int w = 0; w < wid; w++) base += sh[w];
-#pragma unroll
-	for (int k = 0; k < 4; k++) { if (e0 + k < tot) ptr[e0 + k] = base; base += c[k]; }
-	if (e0 < tot && tot <= e0 + 4) ptr[tot] = base;          // the thread that holds the last element: the end offset
-	if (tot == 0 && blockIdx.x == 0 && threadIdx.x == 0) ptr[0] = 0;
-}
-
-// ---- ingest 3: the lists.  Same walk as ingest 1 over the TILED rows; the sample indices of a variant's
-// missing genotypes of range g go to idx[ptr[g M + v] ..), ascending; the carriers of a variant that
-// s3_ingest_clist_kernel gave a list to cidx[cptr[v] ..) as sample | code << 30, ascending.
-__global__ void __launch_bounds__(256)
-s3_ingest_fill_kernel(const uint8_t *__restrict__ tiles, int N, int M, int ntile, const uint8_t *__restrict__ ovf,
-	const unsigned *__restrict__ ptr, unsigned *__restrict__ idx,
-	const uint8_t *__restrict__ corient, const unsigned *__restrict__ cptr, unsigned *__restrict__ cidx)
-{
-	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-	const int frag = blockIdx.x * 4 + wid, nfrag = (M + 15) / 16;
-	if (frag >= nfrag) return;
-	const int r = lane & 15, kg = lane >> 4, v = frag * 16 + r;
-	const bool live = v < M && !ovf[v];
-	const int orient = v < M ? corient[v] : 0;
-	const uint32_t zx = orient == 2 ? 0xAAAAAAAAu : 0u;      // flipped: the carriers are the codes other than 2
-	const uint8_t *src = tiles + (size_t)frag * ntile * 1024 + s3_dma_lane(lane) * 16;
-	constexpr int UN = 4;
-	int rg = -1, tend = 0;
-	unsigned off = 0, coff = orient ? cptr[v] : 0u;
-	const bool any_listed = __ballot(orient != 0) != 0;
-	for (int t0 = 0; t0 < ntile; t0 += UN) {
-		uint4 w[UN];
-#pragma unroll
-		for (int j = 0; j < UN; j++) {
-			w[j] = make_uint4(0u, 0u, 0u, 0u);
-			if (t0 + j < ntile) w[j] = *reinterpret_cast<const uint4 *>(src + (size_t)(t0 + j) * 1024);
-		}
-#pragma unroll
-		for (int j = 0; j < UN; j++) {
-			const int t = t0 + j;
-			if (t >= ntile) break;
-			while (t >= tend) { rg++; tend = s3_range_t0(rg + 1, ntile); off = live ? ptr[(size_t)rg * M + v] : 0u; }
-			const uint32_t d[4] = {w[j].x, w[j].y, w[j].z, w[j].w};
-			uint32_t m[4], z[4] = {0u, 0u, 0u, 0u};
-			int c = 0, cc = 0;
-			const int s0 = t * 256 + kg * 64;
-#pragma unroll
-			for (int u = 0; u < 4; u++) {
-				m[u] = live ? (d[u] & (d[u] >> 1) & 0x55555555u) : 0u;
-				c += __popc(m[u]);
-			}
-			if (any_listed) {
-				const bool full = (t + 1) * 256 <= N;     // (the padding samples hold code 0: carriers of a flipped variant otherwise)
-#pragma unroll
-				for (int u = 0; u < 4; u++) {
-					uint32_t x = d[u] ^ zx;
-					if (!full) {
-						const int keep = N - s0 - 16 * u;
-						x &= (keep >= 16) ? 0xFFFFFFFFu : ((keep <= 0) ? 0u : ((1u << (2 * keep)) - 1u));
-					}
-					z[u] = orient ? ((x | (x >> 1)) & 0x55555555u) : 0u;
-					cc += __popc(z[u]);
-				}
-			}
-			if (!__ballot((c | cc) != 0)) continue;
-			// exclusive prefix over the four kg lanes of the variant
-			if (__ballot(c != 0)) {
-				const int c0 = __shfl(c, r, 64), c1 = __shfl(c, r + 16, 64), c2 = __shfl(c, r + 32, 64), c3 = __shfl(c, r + 48, 64);
-				unsigned o = off + (kg > 0 ? c0 : 0) + (kg > 1 ? c1 : 0) + (kg > 2 ? c2 : 0);
-				off += (unsigned)(c0 + c1 + c2 + c3);
-#pragma unroll
-				for (int u = 0; u < 4; u++) {
-					uint32_t mm = m[u];
-					while (mm) {
-						const int b = __ffs(mm) - 1;
-						mm &= mm - 1;
-						idx[o++] = (unsigned)(t * 256 + kg * 64 + u * 16 + (b >> 1));
-					}
-				}
-			}
-			if (__ballot(cc != 0)) {
-				const int c0 = __shfl(cc, r, 64), c1 = __shfl(cc, r + 16, 64), c2 = __shfl(cc, r + 32, 64), c3 = __shfl(cc, r + 48, 64);
-				unsigned o = coff + (kg > 0 ? c0 : 0) + (kg > 1 ? c1 : 0) + (kg > 2 ? c2 : 0);
-				coff += (unsigned)(c0 + c1 + c2 + c3);
-#pragma unroll
-				for (int u = 0; u < 4; u++) {
-					uint32_t mm = z[u];
-					while (mm) {
-						const int b = __ffs(mm) - 1;
-						mm &= mm - 1;
-						cidx[o++] = (unsigned)(s0 + u * 16 + (b >> 1)) | (((d[u] >> b) & 3u) << 30);
-					}
-				}
-			}
-		}
-	}
-}
-
 // ---- T3: sums of the fixed-point score values over a variant's missing samples, per sample range.
 // Q: [N][P] int64, the values the limb tiles hold (digits x position scale).  A task = (range g, variant v),
 // taken by PP lanes: lane c of the task gathers column c of every listed sample (a row of Q is P x 8 contiguous
 // bytes) and keeps hi = sum q >> 32, lo = sum q & 0xFFFFFFFF -- exact, whatever the order.  A workgroup works
-// on one range (blockIdx % S3_NR): with blocks dealt round-robin over the XCDs an L2 sees two ranges of Q
-// (1/8 of the table).  part: [S3_NR][M][P][2] int64.
+// on one range (blockIdx % nr): with blocks dealt round-robin over the XCDs an L2 sees two of sixteen ranges of Q
+// (1/8 of the table).  part: [nr][M][P][2] int64.  The lists: kern_lists.h.
 template <int PP>
 __global__ void __launch_bounds__(256, PP <= 16 ? 8 : 7)    /* few enough registers (64 / 72) to sit beside score3_kernel's workgroup on a CU */
-s3_t3_kernel(int M, int P, const long long *__restrict__ Q, const unsigned *__restrict__ ptr, const unsigned *__restrict__ idx,
-	long long *__restrict__ part)
+s3_t3_kernel(int M, int P, const long long *__restrict__ Q, S3Lists L, long long *__restrict__ part)
 {
 	constexpr int TPW = 64 / PP;                       // tasks per wave
 	constexpr int NB = 1;                              // index loads in flight per lane: NB x PP gathers behind them
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-	const int g = blockIdx.x % S3_NR, chunk = blockIdx.x / S3_NR;
+	const int g = blockIdx.x % L.nr, chunk = blockIdx.x / L.nr;
+	const unsigned *__restrict__ idx = L.idx;
 	const int c = lane % PP, tk = lane / PP;
 	const int v = (chunk * 4 + wid) * TPW + tk;
 	unsigned e0 = 0, e1 = 0;
-	if (v < M) { e0 = ptr[(size_t)g * M + v]; e1 = ptr[(size_t)g * M + v + 1]; }
+	if (v < M) { e0 = L.lstart[(size_t)g * L.ld + v]; e1 = e0 + (unsigned)max(0, L.lcnt[(size_t)g * L.ld + v]); }
 	long long hi = 0, lo = 0;
 	const int gbase = lane - c;                        // first lane of this task
 	for (unsigned e = e0; __any(e < e1); e += NB * PP) {
@@ -719,13 +579,12 @@ s3_t3_kernel(int M, int P, const long long *__restrict__ Q, const unsigned *__re
 
 // sums of the per-range partials: t3[v][c] = {hi, lo}
 __global__ void __launch_bounds__(256)
-s3_t3_sum_kernel(size_t n, const long long *__restrict__ part, long long *__restrict__ t3)
+s3_t3_sum_kernel(size_t n, int nr, const long long *__restrict__ part, long long *__restrict__ t3)
 {
 	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // over M x P x 2
 	if (i >= n) return;
 	long long s = 0;
-#pragma unroll
-	for (int g = 0; g < S3_NR; g++) s += part[(size_t)g * n + i];
+	for (int g = 0; g < nr; g++) s += part[(size_t)g * n + i];
 	t3[i] = s;
 }
 

@@ -30,12 +30,17 @@ struct S3Plan {
 	int rem;        // leftover variant tiles = vt % wpg
 	int f;          // pieces per leftover variant tile (0 if rem == 0)
 	int ipg;        // items per group = rf * wpg + rem * f
+	// row-major input (score3_kernel<.., RM = true>): the rows as the caller holds them, no tiles
+	int nrow;       // rows (variants) that exist: the loaders never touch a row >= nrow
+	unsigned long long bpv;   // bytes per row (a multiple of 16, >= 64 ntile)
 };
 
-static inline S3Plan s3_plan(size_t M, int ntile, int grid, int fpw)
+static inline S3Plan s3_plan(size_t M, int ntile, int grid, int fpw, size_t bpv = 0)
 {
 	S3Plan p{};
 	p.ntile = ntile;
+	p.nrow = (int)M;
+	p.bpv = bpv;
 	p.nfrag = (int)((M + 15) / 16);
 	p.fpw = fpw;
 	p.vt = (p.nfrag + fpw - 1) / fpw;
@@ -82,6 +87,10 @@ __host__ __device__ __forceinline__ int s3_pos(int s) { return ((s & 3) << 2) | 
 // codes at odd positions are used where they stand, two bits up -- their limb digits carry q / 4
 __host__ __device__ __forceinline__ int s3_scale(int e) { return (e & 1) ? 4 : 1; }
 
-// sample ranges of the missing-genotype lists (s3_t3_kernel): range g = tiles [g ntile / S3_NR, (g + 1) ntile / S3_NR)
+// sample ranges of the missing-genotype lists (kern_lists.h, s3_t3_kernel): range g of nr = tiles [g ntile / nr,
+// (g + 1) ntile / nr).  nr = 16 for long rows (a workgroup of the T3 pass gathers from 1/16 of the table Q, so an
+// XCD's L2 sees 1/8 of it), fewer for short ones (a wave of the list builder wants ~8 KiB of a row: at
+// N = 50 000 sixteen ranges were 800 000 waves of 780 bytes, bound by the launch rate).
 #define S3_NR 16
-__host__ __device__ __forceinline__ int s3_range_t0(int g, int ntile) { return (int)((long long)g * ntile / S3_NR); }
+__host__ __device__ __forceinline__ int s3_nranges(int ntile) { const int n = (ntile * 64 + 8191) / 8192; return n < 1 ? 1 : (n > S3_NR ? S3_NR : n); }
+__host__ __device__ __forceinline__ int s3_range_t0(int g, int ntile, int nr) { return (int)((long long)g * ntile / nr); }

@@ -74,21 +74,28 @@ static int fail(int code, const char *fmt, ...)
 // ---------------------------------------------------------------------------
 // host side
 
-// A block of variants in the tiled device layout (s3_layout.h) with the lists of its missing genotypes.
-// Depends on the number of samples only: one block can be scanned with any model of that many samples.
+// A block of variants: the 2-bit rows as they came (row-major: the contraction kernel's loaders read them as they
+// are) with the sparse side the scan needs -- the positions of the missing genotypes and, in a resident block,
+// the carrier lists of the rare variants (kern_lists.h).  Depends on the number of samples only: one block can be
+// scanned with any model of that many samples.  lists_only: the scratch of the row-major scan calls -- the rows
+// stay where the caller has them (ext_rows), no carrier lists.
 struct sgx_block {
 	int device = 0;
-	int N = 0, ntile = 0;
+	int N = 0, ntile = 0, nr = 1;
 	size_t cap = 0;              // variants it can hold
 	size_t M = 0;                // variants loaded
-	uint8_t *tiles = nullptr;    // [ceil(cap / 16)][ntile][1024]
-	int *cnt = nullptr;          // [S3_NR][cap] listed missing genotypes per (sample range, variant)
-	unsigned *ptr = nullptr;     // [S3_NR * cap + 1] offsets into idx in (range, variant) order
-	unsigned *idx = nullptr;     // sample indices of the listed missing genotypes
-	size_t idx_cap = 0;
-	int *n3 = nullptr;           // [cap] missing genotypes per variant (listed or not)
-	uint8_t *ovf = nullptr;      // [cap] 1 = not listed (too many): the scan takes the FP64 kernel for it
-	unsigned long long *piece = nullptr;   // sums of 1024-element pieces of the (range, variant) counts (load-time scratch)
+	bool lists_only = false;
+	uint8_t *rows = nullptr;     // [cap][bpv] the block's copy of the rows
+	size_t bpv = 0;              // bytes per row of that copy = sgx_row_stride(N)
+	const uint8_t *ext_rows = nullptr; size_t ext_bpv = 0;   // lists_only: the rows of the scan in flight
+	// missing genotypes (S3Lists)
+	unsigned *idx = nullptr; size_t idx_cap = 0;
+	unsigned *cursor = nullptr;  // [S3_NSUB x S3_CURSOR_STRIDE]
+	unsigned *lstart = nullptr;  // [nr][cap]
+	int *lcnt = nullptr;         // [nr][cap]
+	int *nzp = nullptr, *n2p = nullptr;    // [nr][cap] non-zero codes / codes 2 per (range, variant) (resident blocks)
+	int *n3 = nullptr;           // [cap] listed missing genotypes per variant
+	uint8_t *ovf = nullptr;      // [cap] 1 = not listed (the pool was full): the scan takes the FP64 kernel for it
 	// carrier lists of the rare variants (at most SPA5_NNZ carriers): what the per-variant SPA kernels walk
 	int *nzv = nullptr, *n2v = nullptr;    // [cap] non-zero codes / codes 2 per variant (load-time scratch)
 	unsigned *cptr = nullptr;    // [cap + 1] start of a variant's list in cidx
@@ -96,6 +103,8 @@ struct sgx_block {
 	size_t cidx_cap = 0;
 	uint8_t *corient = nullptr;  // [cap] 0 no list, 1 list of the non-zero codes, 2 of the codes other than 2 (AF > 0.5)
 	hipEvent_t ready = nullptr;  // recorded behind the last load: scans on other streams wait for it
+	hipEvent_t last_read = nullptr;   // recorded behind the last scan that reads the block: a reload waits for it
+	bool was_read = false;
 };
 
 struct sgx_handle {
@@ -116,7 +125,6 @@ struct sgx_handle {
 	bool spa5_attr_set[3] = {false, false, false};
 	bool mom_attr_set[3] = {false, false, false};   // per input type: the moments kernels' dynamic LDS size has been raised
 	uint8_t *scr5 = nullptr; int *cur5 = nullptr; int nwg5 = 0;   // spa5_kernel: per-workgroup lists, queue cursor
-	bool spa5_small0 = false;
 	int spa_abl = 0;                  // timing experiments (wrong results)
 	bool force_exact = false;         // test hook: every SPA variant takes the exact exp/log kernels
 	// exact-integer MFMA score path (kern_score_mfma.h)
@@ -150,6 +158,7 @@ struct sgx_handle {
 	double *pin_out[2] = {nullptr, nullptr}; uint8_t *pin_valid[2] = {nullptr, nullptr};   // pinned host
 	int *pipe_flag = nullptr, *h_pipe_flag = nullptr;
 	hipEvent_t ev_h2d = nullptr;
+	hipEvent_t ev_copy[2] = {nullptr, nullptr}, ev_done[2] = {nullptr, nullptr};   // sgx_block_load: chunk copied / chunk read
 	uint8_t *stage_pk = nullptr; size_t stage_pk_cap = 0;   // burden: packed rows, CSR and tables
 	double *ds_part = nullptr; size_t ds_part_cap = 0;       // dosage score kernels: per-split partial sums
 	double *stage_out = nullptr; uint8_t *stage_valid = nullptr; size_t stage_out_cap = 0;
@@ -157,11 +166,11 @@ struct sgx_handle {
 	hipEvent_t evk[2] = {nullptr, nullptr};    // around the contraction kernel alone (stats.ms_kernel)
 	bool evk_set = false;
 	sgx_stats stats{};
-	bool force_v1 = false;            // SAIGEHIP_SCORE_V1=1: gather kernel instead of the MFMA path
+	bool force_v1 = false;            // "score_v1" option: gather kernel instead of the MFMA path
 	bool stats_pending = false;
 	// dense g_pos / g_neg fallback of the last device-resident call, launched by the next sync if that call turned
 	// out to need it (launch_spa, lazy_dense)
-	struct { bool active = false; RowsRef rr{}; size_t M = 0; double *out8 = nullptr; } pend_dense;
+	struct { bool active = false; RowsRef rr{}; size_t M = 0; double *out8 = nullptr; const sgx_block *blk = nullptr; } pend_dense;
 	// Lanes ("lanes" option, 1..SGX_MAX_LANES): device-resident scans go round-robin over this handle and
 	// its twins, each with its own stream and workspace (the model arrays are shared), so that the SPA stage
 	// of one block of variants runs while the score stage of the next one streams the genotypes, and -- where
@@ -311,8 +320,7 @@ static int alloc_workspace(sgx_handle *h)
 	if (!h->md.quant) {
 		// workgroups of the per-variant kernels, each with its scratch lists: 4 per CU where a packed row is
 		// short (128-thread workgroups, see the launch), else one
-		h->spa5_small0 = [] { const char *e = getenv("SAIGEHIP_SPA5_SMALL0"); return e && e[0] == '1'; }();   // (experiment, launch_spa)
-		h->nwg5 = ((size_t)((N + 63) / 64) * 16 <= 32 * 1024 || h->spa5_small0) ? h->n_cu * 4 : h->n_cu;
+		h->nwg5 = ((size_t)((N + 63) / 64) * 16 <= 32 * 1024) ? h->n_cu * 4 : h->n_cu;
 		HIPCHK(hipMalloc((void **)&h->scr5, (size_t)h->nwg5 * spa5_wg_bytes(N)));
 		HIPCHK(hipMalloc((void **)&h->cur5, 8 * sizeof(int)));   // [0], [1] spa5_kernel queues; [2], [3] spa4_moments' item queue; [4], [5] spa5_kernel on the blocks' lists
 	}
@@ -537,7 +545,6 @@ extern "C" int sgx_init(const sgx_model *m, int device, sgx_handle **out)
 	rc = alloc_workspace(h);
 	if (rc) { sgx_free(h); return rc; }
 #undef TRY
-	{ const char *e = getenv("SAIGEHIP_SCORE_V1"); h->force_v1 = e && e[0] == '1'; }
 	*out = h;
 	return SGX_OK;
 }
@@ -575,6 +582,7 @@ extern "C" void sgx_free(sgx_handle *h)
 	(void)hipFree(h->pipe_flag);
 	if (h->h_pipe_flag) (void)hipHostFree(h->h_pipe_flag);
 	if (h->ev_h2d) (void)hipEventDestroy(h->ev_h2d);
+	for (int k = 0; k < 2; k++) { if (h->ev_copy[k]) (void)hipEventDestroy(h->ev_copy[k]); if (h->ev_done[k]) (void)hipEventDestroy(h->ev_done[k]); }
 	if (h->cstream) (void)hipStreamDestroy(h->cstream);
 	(void)hipFree(h->stage_in); (void)hipFree(h->stage_out); (void)hipFree(h->stage_valid); (void)hipFree(h->stage_pk); (void)hipFree(h->ds_part);
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
@@ -724,14 +732,6 @@ static int launch_spa(sgx_handle *h, RowsRef rr, size_t M, double *out8, bool la
 					l5, st, rr, md, h->recs, h->counters, h->fb_x2, h->fb_x2, h->cur5 + 1, \
 					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5, only5, ws5, 4); \
 			} else {                                                                         \
-				/* (experiment SAIGEHIP_SPA5_SMALL0=1: the series kernel of a block scan in the 128-thread form, four \
-				   workgroups per CU, no row staged -- a variant without a list reads its row from global memory) */ \
-				constexpr int IN5 = INPUT == IN_2BIT ? INPUT : IN_2BIT;                      \
-				if (h->spa5_small0 && INPUT == IN_2BIT && rr.cptr != nullptr && !only5)      \
-				hipLaunchKernelGGL((spa5_kernel<KK, IN5, 0, 128>), dim3((unsigned)h->nwg5), dim3(128), \
-					0, st, rr, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
-					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, (size_t)0, only5, ws5, 3); \
-				else                                                                         \
 				hipLaunchKernelGGL((spa5_kernel<KK, INPUT, 0, 512>), dim3((unsigned)h->n_cu), dim3(512), \
 					l5, st, rr, md, h->recs, h->counters, h->fb_spa2, h->fb_x2, h->cur5, \
 					h->fallback, h->scr5, out8, h->force_dense ? 1 : 0, fx5, l5, only5, ws5, 3); \
@@ -866,7 +866,7 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 			t->dF = h->dF; t->dX = h->dX; t->dy = h->dy; t->dmu = h->dmu; t->dmu2 = h->dmu2; t->dXM = h->dXM; t->dFl = h->dFl; t->dQ = h->dQ;
 			t->shares_model = true; t->owner = h;
 			t->force_dense = h->force_dense; t->force_v1 = h->force_v1; t->force_exact = h->force_exact;
-			t->spa_abl = h->spa_abl; t->spa5_small0 = h->spa5_small0;
+			t->spa_abl = h->spa_abl;
 			rc = set_dev(t);
 			if (!rc) rc = alloc_workspace(t);
 			if (rc) { sgx_free(t); return rc; }
@@ -957,29 +957,45 @@ extern "C" int sgx_get_stats_total(sgx_handle *h, sgx_stats *st, uint64_t *n_cal
 // ---------------------------------------------------------------------------
 // Genotype blocks (kern_score3.h)
 
+// entries of a block's pools for max_variants rows of n_samp samples
+static size_t block_idx_cap(int32_t n_samp, size_t max_variants)
+{
+	// missing genotypes: room for max(64, N / 128) per variant on average (0.8 % at large N), at least a few
+	// segments per sub-pool; variants that find the pool full take the FP64 kernel
+	return std::min<size_t>(std::max<size_t>(max_variants * std::max<size_t>(64, (size_t)n_samp / 128), (size_t)S3_NSUB * 256), 0xF0000000u);
+}
+static size_t block_cidx_cap(int32_t n_samp, size_t max_variants, size_t cavg)
+{
+	// carrier lists: 1536 entries per variant on average (a log-uniform MAF spectrum from 5e-4 lists ~40 % of the
+	// variants at N = 430 000 with ~3 000 carriers each)
+	return std::min<size_t>(max_variants * std::min<size_t>(cavg, (size_t)n_samp), 0xF0000000u);
+}
+#define SGX_CLIST_AVG 1536
+
 extern "C" size_t sgx_block_bytes(int32_t n_samp, size_t max_variants)
 {
 	if (n_samp <= 0 || max_variants == 0) return 0;
-	const int ntile = 2 * ((n_samp + 511) / 512);
-	const size_t lim = std::max<size_t>(64, (size_t)n_samp / 128);
-	const size_t clist = max_variants * std::min<size_t>(1536, (size_t)n_samp) * 4;       // carrier lists (sgx_block_create)
-	return s3_block_bytes(max_variants, ntile) + max_variants * lim * 4 + clist + max_variants * (S3_NR * 8 + 5 + 13) + 8;
+	const int ntile = 2 * ((n_samp + 511) / 512), nr = s3_nranges(ntile);
+	return max_variants * (size_t)ntile * 64 + block_idx_cap(n_samp, max_variants) * 4 + block_cidx_cap(n_samp, max_variants, SGX_CLIST_AVG) * 4 +
+		max_variants * ((size_t)nr * 16 + 5 + 13) + (size_t)S3_NSUB * S3_CURSOR_STRIDE * 4 + 8;
 }
 
 extern "C" void sgx_block_free(sgx_block *b)
 {
 	if (!b) return;
 	(void)hipSetDevice(b->device);
-	(void)hipFree(b->tiles); (void)hipFree(b->cnt); (void)hipFree(b->ptr); (void)hipFree(b->idx);
-	(void)hipFree(b->n3); (void)hipFree(b->ovf); (void)hipFree(b->piece);
+	if (b->last_read && b->was_read) (void)hipEventSynchronize(b->last_read);    // scans that read it are done
+	(void)hipFree(b->rows); (void)hipFree(b->idx); (void)hipFree(b->cursor); (void)hipFree(b->lstart); (void)hipFree(b->lcnt);
+	(void)hipFree(b->nzp); (void)hipFree(b->n2p); (void)hipFree(b->n3); (void)hipFree(b->ovf);
 	(void)hipFree(b->nzv); (void)hipFree(b->n2v); (void)hipFree(b->cptr); (void)hipFree(b->cidx); (void)hipFree(b->corient);
 	if (b->ready) (void)hipEventDestroy(b->ready);
+	if (b->last_read) (void)hipEventDestroy(b->last_read);
 	delete b;
 }
 
-extern "C" int sgx_block_create(int32_t n_samp, size_t max_variants, int device, sgx_block **out)
+// cavg: carrier-list entries per variant on average (resident blocks); lists_only: the scratch of a row-major scan
+static int block_create(int32_t n_samp, size_t max_variants, int device, bool lists_only, size_t cavg, sgx_block **out)
 {
-	if (!out) return fail(SGX_EINVAL, "sgx_block_create: NULL argument");
 	*out = nullptr;
 	if (n_samp <= 0 || max_variants == 0 || max_variants > 0x7fffffffu / S3_NR)
 		return fail(SGX_EINVAL, "sgx_block_create: n_samp = %d, max_variants = %zu", n_samp, max_variants);
@@ -987,69 +1003,116 @@ extern "C" int sgx_block_create(int32_t n_samp, size_t max_variants, int device,
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SGX_ENODEV, "sgx_block_create: no HIP device available");
 	if (device < 0 || device >= ndev) return fail(SGX_EINVAL, "sgx_block_create: device %d out of range", device);
 	sgx_block *b = new sgx_block();
-	b->device = device; b->N = n_samp; b->ntile = 2 * ((n_samp + 511) / 512); b->cap = max_variants;
-	// the list holds up to max(64, N / 128) missing genotypes per variant on average (0.8 % at large N);
-	// variants beyond a full list, or with more than 16 times that, take the FP64 kernel
-	b->idx_cap = std::min<size_t>(max_variants * std::max<size_t>(64, (size_t)n_samp / 128), 0xF0000000u);
-	// carrier lists: 1536 entries per variant on average (a log-uniform MAF spectrum from 5e-4 lists ~40 % of the
-	// variants at N = 430 000 with ~3 000 carriers each); SAIGEHIP_CLIST_CAP overrides the average (tests)
-	size_t cavg = 1536;
-	if (const char *e5 = getenv("SAIGEHIP_CLIST_CAP")) cavg = (size_t)std::max(0ll, atoll(e5));
-	b->cidx_cap = std::min<size_t>(max_variants * std::min<size_t>(cavg, (size_t)n_samp), 0xF0000000u);
+	b->device = device; b->N = n_samp; b->ntile = 2 * ((n_samp + 511) / 512); b->nr = s3_nranges(b->ntile); b->cap = max_variants;
+	b->lists_only = lists_only;
+	b->bpv = (size_t)b->ntile * 64;
+	b->idx_cap = block_idx_cap(n_samp, max_variants);
+	b->cidx_cap = lists_only ? 0 : block_cidx_cap(n_samp, max_variants, cavg);
+	const size_t nrc = (size_t)b->nr * max_variants;
 	hipError_t e = hipSetDevice(device);
-	if (e == hipSuccess) e = hipMalloc((void **)&b->tiles, s3_block_bytes(max_variants, b->ntile));
-	if (e == hipSuccess) e = hipMalloc((void **)&b->nzv, max_variants * sizeof(int));
-	if (e == hipSuccess) e = hipMalloc((void **)&b->n2v, max_variants * sizeof(int));
-	if (e == hipSuccess) e = hipMalloc((void **)&b->cptr, (max_variants + 1) * sizeof(unsigned));
-	if (e == hipSuccess) e = hipMalloc((void **)&b->cidx, std::max<size_t>(b->cidx_cap, 1) * sizeof(unsigned));
-	if (e == hipSuccess) e = hipMalloc((void **)&b->corient, max_variants);
-	if (e == hipSuccess) e = hipMalloc((void **)&b->cnt, (size_t)S3_NR * max_variants * sizeof(int));
-	if (e == hipSuccess) e = hipMalloc((void **)&b->ptr, ((size_t)S3_NR * max_variants + 1) * sizeof(unsigned));
+	if (e == hipSuccess && !lists_only) e = hipMalloc((void **)&b->rows, max_variants * b->bpv);
 	if (e == hipSuccess) e = hipMalloc((void **)&b->idx, b->idx_cap * sizeof(unsigned));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->cursor, (size_t)S3_NSUB * S3_CURSOR_STRIDE * sizeof(unsigned));
+	if (e == hipSuccess) e = hipMemset(b->cursor, 0, (size_t)S3_NSUB * S3_CURSOR_STRIDE * sizeof(unsigned));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->lstart, nrc * sizeof(unsigned));
+	if (e == hipSuccess) e = hipMalloc((void **)&b->lcnt, nrc * sizeof(int));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->n3, max_variants * sizeof(int));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->ovf, max_variants);
-	if (e == hipSuccess) e = hipMalloc((void **)&b->piece, (((size_t)S3_NR * max_variants + 1023) / 1024 + 1) * sizeof(unsigned long long));
+	if (!lists_only) {
+		if (e == hipSuccess) e = hipMalloc((void **)&b->nzp, nrc * sizeof(int));
+		if (e == hipSuccess) e = hipMalloc((void **)&b->n2p, nrc * sizeof(int));
+		if (e == hipSuccess) e = hipMalloc((void **)&b->nzv, max_variants * sizeof(int));
+		if (e == hipSuccess) e = hipMalloc((void **)&b->n2v, max_variants * sizeof(int));
+		if (e == hipSuccess) e = hipMalloc((void **)&b->cptr, (max_variants + 1) * sizeof(unsigned));
+		if (e == hipSuccess) e = hipMalloc((void **)&b->cidx, std::max<size_t>(b->cidx_cap, 1) * sizeof(unsigned));
+		if (e == hipSuccess) e = hipMalloc((void **)&b->corient, max_variants);
+	}
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&b->ready, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&b->last_read, hipEventDisableTiming);
 	if (e != hipSuccess) { sgx_block_free(b); return fail(e == hipErrorOutOfMemory ? SGX_ENOMEM : SGX_EHIP, "sgx_block_create: %s", hipGetErrorString(e)); }
 	*out = b;
 	return SGX_OK;
 }
 
-// rows [v_first, v_first + m) of the block from row-major device rows: tiles + counts (any number of
-// calls, v_first a multiple of 16), then block_finish once for the lists
+extern "C" int sgx_block_create(int32_t n_samp, size_t max_variants, int device, sgx_block **out)
+{
+	if (!out) return fail(SGX_EINVAL, "sgx_block_create: NULL argument");
+	return block_create(n_samp, max_variants, device, false, SGX_CLIST_AVG, out);
+}
+
+// test hook: a resident block whose carrier lists hold `clist_avg` entries per variant on average (the later
+// variants of a block go unlisted and have their rows scanned by the SPA kernels)
+extern "C" int sgx_block_create_ex(int32_t n_samp, size_t max_variants, int device, long long clist_avg, sgx_block **out)
+{
+	if (!out || clist_avg < 0) return fail(SGX_EINVAL, "sgx_block_create_ex: bad argument");
+	return block_create(n_samp, max_variants, device, false, (size_t)clist_avg, out);
+}
+
+static S3Lists block_lists(const sgx_block *b)
+{
+	S3Lists L{};
+	L.idx = b->idx; L.idx_cap = (unsigned)b->idx_cap; L.cursor = b->cursor; L.lstart = b->lstart; L.lcnt = b->lcnt;
+	L.nzp = b->nzp; L.n2p = b->n2p; L.ld = b->cap; L.nr = b->nr;
+	L.nsub = (int)std::max<size_t>(1, std::min<size_t>(S3_NSUB, (b->cap * (size_t)b->nr + 3) / 4));
+	return L;
+}
+static RowsRef block_rows(const sgx_block *b)
+{
+	if (b->lists_only) return RowsRef{b->ext_rows, b->ext_bpv, 0, nullptr, nullptr, nullptr};
+	return RowsRef{b->rows, b->bpv, 0, b->cptr, b->cidx, b->corient};
+}
+
+// rows [v_first, v_first + m) of the block from row-major device rows: ONE pass over the rows lists their missing
+// genotypes (and, into a resident block, copies them and counts the carriers); any number of calls, then
+// block_finish once
 static int block_put_rows(sgx_block *b, const uint8_t *rows_dev, size_t bpv, size_t v_first, size_t m, hipStream_t st)
 {
-	const int nfrag = (int)((m + 15) / 16);
-	hipLaunchKernelGGL(s3_ingest_tile_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, rows_dev, bpv, b->N, (int)m, b->ntile,
-		b->tiles + (v_first / 16) * (size_t)b->ntile * 1024, b->cnt + v_first, b->cap, b->nzv + v_first, b->n2v + v_first);
+	const unsigned grid = (unsigned)((m * (size_t)b->nr + 3) / 4);
+	const S3Lists L = block_lists(b);
+	if (b->lists_only)
+		hipLaunchKernelGGL((s3_lists_kernel<8, false, false>), dim3(grid), dim3(256), 0, st, rows_dev, bpv, b->N, (int)m, (int)v_first, b->ntile, L,
+			(uint8_t *)nullptr, (size_t)0);
+	else
+		hipLaunchKernelGGL((s3_lists_kernel<8, true, true>), dim3(grid), dim3(256), 0, st, rows_dev, bpv, b->N, (int)m, (int)v_first, b->ntile, L,
+			b->rows, b->bpv);
 	HIPCHK(hipGetLastError());
 	return SGX_OK;
 }
 
 static int block_finish(sgx_block *b, size_t M, hipStream_t st)
 {
-	const size_t lim = 16 * std::max<size_t>(64, (size_t)b->N / 128);
-	const size_t tot = (size_t)S3_NR * M;
-	const int npiece = (int)((tot + 1023) / 1024);
-	hipLaunchKernelGGL(s3_ingest_count_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, b->cap, (int)std::min<size_t>(lim, 0x7fffffff), b->cnt, b->n3, b->ovf);
-	hipLaunchKernelGGL(s3_ingest_budget_kernel, dim3(1), dim3(1024), 0, st, (int)M, (unsigned)b->idx_cap, b->n3, b->ovf);
-	hipLaunchKernelGGL(s3_ingest_piece_kernel, dim3((unsigned)npiece), dim3(256), 0, st, (int)M, b->cap, b->cnt, b->ovf, b->piece);
-	hipLaunchKernelGGL(s3_ingest_piece_scan_kernel, dim3(1), dim3(1024), 0, st, npiece, b->piece);
-	hipLaunchKernelGGL(s3_ingest_ptr_kernel, dim3((unsigned)npiece), dim3(256), 0, st, (int)M, b->cap, b->cnt, b->ovf, b->piece, b->ptr);
-	hipLaunchKernelGGL(s3_ingest_clist_count_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, b->N, SPA5_NNZ, b->nzv, b->n2v, b->n3, b->corient);
-	hipLaunchKernelGGL(s3_ingest_clist_kernel, dim3(1), dim3(1024), 0, st, (int)M, (unsigned)b->cidx_cap, b->nzv, b->cptr, b->corient);
-	const int nfrag = (int)((M + 15) / 16);
-	hipLaunchKernelGGL(s3_ingest_fill_kernel, dim3((unsigned)((nfrag + 3) / 4)), dim3(256), 0, st, b->tiles, b->N, (int)M, b->ntile, b->ovf, b->ptr, b->idx,
-		b->corient, b->cptr, b->cidx);
+	const S3Lists L = block_lists(b);
+	hipLaunchKernelGGL(s3_lists_finish_kernel, dim3((unsigned)((std::max<size_t>(M, S3_NSUB) + 255) / 256)), dim3(256), 0, st, (int)M, L, b->n3, b->ovf,
+		b->lists_only ? (int *)nullptr : b->nzv, b->lists_only ? (int *)nullptr : b->n2v);
+	if (!b->lists_only) {
+		hipLaunchKernelGGL(s3_ingest_clist_count_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, b->N, SPA5_NNZ, b->nzv, b->n2v, b->n3, b->corient);
+		hipLaunchKernelGGL(s3_ingest_clist_kernel, dim3(1), dim3(1024), 0, st, (int)M, (unsigned)b->cidx_cap, b->nzv, b->cptr, b->corient);
+		hipLaunchKernelGGL((s3_clist_fill_kernel<8>), dim3((unsigned)((M * (size_t)b->nr + 3) / 4)), dim3(256), 0, st, b->rows, b->bpv, b->N, (int)M, b->ntile, L,
+			b->corient, b->cptr, b->cidx);
+	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(b->ready, st));
 	b->M = M;
 	return SGX_OK;
 }
 
+// a (re)load of a block: the stream that writes it waits for the scans that still read it; a lane of this handle
+// whose deferred dense pass (launch_spa, lazy_dense) still points at the block is brought to its end first
+static int sync_lane(sgx_handle *h);
+static int block_begin_load(sgx_handle *h, sgx_block *b, hipStream_t st)
+{
+	sgx_handle *p = h->owner ? h->owner : h;
+	sgx_handle *lanes[4] = {p, p->twins[0], p->twins[1], p->twins[2]};
+	for (sgx_handle *l : lanes) if (l && l->pend_dense.active && l->pend_dense.blk == b) { int rc = sync_lane(l); if (rc) return rc; }
+	if (b->was_read) HIPCHK(hipStreamWaitEvent(st, b->last_read, 0));
+	b->M = 0;
+	return SGX_OK;
+}
+
 static int check_block_args(sgx_handle *h, sgx_block *b, size_t bpv, size_t M, const char *who)
 {
 	if (!h || !b) return fail(SGX_EINVAL, "%s: NULL argument", who);
+	if (b->lists_only) return fail(SGX_EINVAL, "%s: not a resident block", who);
 	if (b->device != h->device) return fail(SGX_EINVAL, "%s: block and handle are on different devices", who);
 	if (M == 0 || M > b->cap) return fail(SGX_EINVAL, "%s: %zu variants, the block holds up to %zu", who, M, b->cap);
 	if (bpv % 16 != 0 || bpv < (size_t)b->ntile * 64)
@@ -1064,25 +1127,14 @@ extern "C" int sgx_block_load_dev(sgx_handle *h, sgx_block *b, const uint8_t *pa
 	if (!packed_dev || ((uintptr_t)packed_dev & 15u)) return fail(SGX_EINVAL, "sgx_block_load_dev: packed_dev must be a 16-byte aligned device pointer");
 	rc = set_dev(h);
 	if (rc) return rc;
+	rc = block_begin_load(h, b, h->stream);
+	if (rc) return rc;
 	rc = block_put_rows(b, packed_dev, bpv, 0, M, h->stream);
 	if (rc) return rc;
 	return block_finish(b, M, h->stream);
 }
 
 extern "C" size_t sgx_block_variants(const sgx_block *b) { return b ? b->M : 0; }
-
-// Per NBF the instantiation of score3_kernel: fragments per consumer wave, consumer / row-loader / B-loader
-// waves, tiles ahead (rows / B), column groups of the consumer waves -- what fits 160 KiB of LDS and the registers
-// of that many waves, the fastest of the forms measured with tools/score3_bench (tools/README.md).  Column groups
-// (two waves sharing the row pieces, each with half of the columns) measured 7 % faster than one group at 12
-// fragments on the tool's random operands and 4 % SLOWER in the scan (real rows are mostly zero codes: the chip
-// clocks higher and the doubled unpack then costs more than the saved LDS reads): one group everywhere.
-#define S3_FOR_EACH_NBF(X) \
-	X(2, 4, 8, 3, 1, 3, 2, 1) X(3, 4, 8, 3, 1, 3, 1, 1) X(4, 4, 8, 3, 1, 2, 2, 1) X(5, 3, 8, 3, 1, 3, 1, 1) X(6, 3, 8, 3, 1, 3, 1, 1) \
-	X(7, 4, 4, 2, 2, 3, 1, 1) X(8, 4, 4, 2, 2, 3, 1, 1) X(9, 4, 4, 2, 2, 3, 1, 1) X(10, 4, 4, 2, 2, 3, 1, 1) X(11, 4, 4, 2, 2, 3, 1, 1) \
-	X(12, 3, 4, 2, 2, 3, 1, 1) X(13, 3, 4, 2, 2, 3, 1, 1) X(14, 2, 4, 2, 2, 3, 1, 1) X(15, 2, 4, 2, 2, 3, 1, 1) X(16, 2, 4, 2, 2, 3, 1, 1)
-// (SAIGEHIP_S3_ALT=1, timing experiments: the other candidate of a fragment count, key 100 + NBF)
-#define S3_FOR_EACH_ALT(X) X(112, 6, 4, 2, 2, 3, 1, 2)
 
 template <typename T>
 static int ensure_buf(sgx_handle *h, T **p, size_t *cap, size_t need)
@@ -1097,8 +1149,9 @@ static int ensure_buf(sgx_handle *h, T **p, size_t *cap, size_t need)
 	return SGX_OK;
 }
 
-// Scan of a loaded block on this lane's stream: contraction, sparse pass over the missing genotypes, reduction,
-// epilogue, the FP64 kernel for what the lists do not cover, SPA stage.
+// Scan of a block (resident, or the lists of a row-major call with the caller's rows) on this lane's stream: sparse
+// pass over the missing genotypes, contraction, reduction, epilogue, the FP64 kernel for what the lists do not
+// cover, SPA stage.
 static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double *out8, uint8_t *valid, bool lazy_dense = false)
 {
 	const DevModel &md = h->md;
@@ -1106,94 +1159,78 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	hipStream_t st = h->stream;
 	const int NBF = h->mf_nbfv[0] + 1;
 	const int grid = std::max(8, h->n_cu & ~7);
+	const RowsRef rr = block_rows(b);
+	const S3Lists L = block_lists(b);
 	S3Plan pl{};
-	int NCW = 0, NAFW = 0, NCBW = 1;
+	int NCW = 0, NAFW = 0;
 	HIPCHK(hipStreamWaitEvent(st, b->ready, 0));
 	HIPCHK(hipEventRecord(h->ev[0], st));            // (counters and queue cursors: zeroed by s3_reduce_kernel)
-	int rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)(S3_NR + 1) * M * md.P * 2);      // per-range partials, then the totals
+	int rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)(b->nr + 1) * M * md.P * 2);      // per-range partials, then the totals
 	if (rc) return rc;
 	rc = ensure_buf(h, &h->s3_ovf, &h->s3_ovf_cap, M);
 	if (rc) return rc;
-	// sums over the missing samples, on the side stream.  The pass goes FIRST and the contraction kernel waits for
-	// it (SAIGEHIP_T3_ORDER, experiments: 0 = first without the wait, 1 = after the kernel's launch):
+	// Sums over the missing samples, on the side stream, FIRST; the contraction kernel waits for them:
 	//  * with few fragments (3 waves of ~154 registers per SIMD) the pass finds no room beside a resident
 	//    contraction workgroup; launched second it would wait for the kernel's end;
 	//  * from 7 fragments on (2 waves of <= 216 registers) one wave of the pass fits per SIMD, but in the kernel's
-	//    shadow it slows the kernel by what it saves (K = 13, same box: 6.13 / 6.20 ms per step first, 6.23 / 6.23
-	//    after);
-	//  * launched together onto an idle GPU -- with two lanes every other step: this lane's previous step has
-	//    ended, the other lane is in the tail of its SPA stage -- the pass's 25 000 small workgroups and the
-	//    kernel's 256 persistent ones fight for the CUs (a CU holding a wave of the pass per SIMD cannot take a
-	//    contraction workgroup; the workgroups placed late end late, the kernel's work being dealt statically:
-	//    kernel traces show 1.9 ms for the kernel and 1.1 ms for the pass in those steps).  With the wait the pass
-	//    has the GPU for its 0.17 ms (or runs beside the other lane's cumulant pass, where it fits) and the kernel
-	//    starts on free CUs: the same step time (C3 2.36-2.48 ms either way, three same-box pairs), the kernel's
-	//    events 1.07-1.12 ms instead of 1.36-1.42 -- they now time the kernel, not its wait for the pass.
-	static const int t3_order = [] { const char *e = getenv("SAIGEHIP_T3_ORDER"); return e ? atoi(e) : 2; }();
-	const bool t3_after = t3_order == 1;
+	//    shadow it slows the kernel by what it saves (K = 13, same box: 6.13 / 6.20 ms per step first, 6.23 / 6.23 after);
+	//  * launched together onto an idle GPU the pass's 25 000 small workgroups and the kernel's 256 persistent ones
+	//    fight for the CUs (kernel traces: 1.9 ms for the kernel and 1.1 ms for the pass in those steps).
+	// (round 3, tools/README.md: the three orders measured)
 	HIPCHK(hipEventRecord(h->s3_fork, st));                  // (the side stream starts where this stream stands NOW)
 	HIPCHK(hipStreamWaitEvent(h->s3_side, h->s3_fork, 0));
-	auto launch_t3 = [&]() -> int {
+	{
 		hipStream_t s2 = h->s3_side;
 		const int PP = md.P <= 8 ? 8 : md.P <= 16 ? 16 : md.P <= 32 ? 32 : 64;
 		const int tpw = 64 / PP;
 		const unsigned chunks = (unsigned)((M + 4 * tpw - 1) / (4 * tpw));
-		const dim3 g3(chunks * S3_NR);
-		if (PP == 8) hipLaunchKernelGGL(s3_t3_kernel<8>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
-		else if (PP == 16) hipLaunchKernelGGL(s3_t3_kernel<16>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
-		else if (PP == 32) hipLaunchKernelGGL(s3_t3_kernel<32>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
-		else hipLaunchKernelGGL(s3_t3_kernel<64>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, b->ptr, b->idx, h->s3_t3);
+		const dim3 g3(chunks * (unsigned)b->nr);
+		if (PP == 8) hipLaunchKernelGGL(s3_t3_kernel<8>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, L, h->s3_t3);
+		else if (PP == 16) hipLaunchKernelGGL(s3_t3_kernel<16>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, L, h->s3_t3);
+		else if (PP == 32) hipLaunchKernelGGL(s3_t3_kernel<32>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, L, h->s3_t3);
+		else hipLaunchKernelGGL(s3_t3_kernel<64>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, L, h->s3_t3);
 		const size_t n3e = M * (size_t)md.P * 2;
-		hipLaunchKernelGGL(s3_t3_sum_kernel, dim3((unsigned)((n3e + 255) / 256)), dim3(256), 0, s2, n3e, h->s3_t3, h->s3_t3 + (size_t)S3_NR * n3e);
+		hipLaunchKernelGGL(s3_t3_sum_kernel, dim3((unsigned)((n3e + 255) / 256)), dim3(256), 0, s2, n3e, b->nr, h->s3_t3, h->s3_t3 + (size_t)b->nr * n3e);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(h->s3_join, s2));
-		return SGX_OK;
-	};
-	if (!t3_after) { rc = launch_t3(); if (rc) return rc; }
-	const bool t3_join_early = t3_order == 2;
-	if (t3_join_early) HIPCHK(hipStreamWaitEvent(st, h->s3_join, 0));
-	static const bool s3_alt = [] { const char *e = getenv("SAIGEHIP_S3_ALT"); return e && e[0] == '1'; }();
-	switch ((s3_alt && NBF == 12) ? 100 + NBF : NBF) {
-#define S3CASE(KEY_, NAF_, NC_, NLA_, NLB_, DA_, DB_, NCB_)                                                  \
-	case KEY_: {                                                                                          \
-		constexpr int NBF_ = KEY_ % 100;                                                                  \
-		NCW = NC_; NAFW = NAF_; NCBW = NCB_;                                                              \
-		constexpr int NBW_ = (NBF_ + NCB_ - 1) / NCB_, NCV_ = NC_ / NCB_;                                  \
-		pl = s3_plan(M, b->ntile, grid, NAF_ * NCV_);                                                     \
-		rc = ensure_buf(h, &h->s3_slabs, &h->s3_slabs_cap, (size_t)pl.ng * pl.ipg * NC_ * NAF_ * NBW_ * 256); \
+	}
+	HIPCHK(hipStreamWaitEvent(st, h->s3_join, 0));
+	switch (NBF) {
+#define S3CASE(NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_)                                                         \
+	case NBF_: {                                                                                          \
+		NCW = NC_; NAFW = NAF_;                                                                           \
+		pl = s3_plan(M, b->ntile, grid, NAF_ * NC_, rr.bpv);                                              \
+		rc = ensure_buf(h, &h->s3_slabs, &h->s3_slabs_cap, (size_t)pl.ng * pl.ipg * NC_ * NAF_ * NBF_ * 256); \
 		if (rc) return rc;                                                                                \
-		const size_t lds = ((size_t)(DB_ + 1) * 4 * NBF_ + (size_t)(DA_ + 1) * NCV_ * NAF_) * 1024;       \
-		auto kern = score3_kernel<NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_, 0, NCB_>;                         \
+		const size_t lds = s3_lds_bytes(NBF_, NAF_, NC_, DA_, DB_);                                       \
+		auto kern = score3_kernel<NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_, 0, 1, 2, 1>;                      \
 		if (!h->s3_attr[NBF_]) {                                                                          \
 			HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
 			h->s3_attr[NBF_] = true;                                                                      \
 		}                                                                                                 \
 		HIPCHK(hipEventRecord(h->evk[0], st));                                                            \
 		hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (NC_ + NLA_ + NLB_)), lds, st,            \
-			(const uint8_t *)b->tiles, (const uint8_t *)h->dFl, pl, h->s3_slabs, (unsigned long long *)nullptr); \
+			rr.base, (const uint8_t *)h->dFl, pl, h->s3_slabs, (unsigned long long *)nullptr);            \
 		HIPCHK(hipEventRecord(h->evk[1], st));                                                            \
 		h->evk_set = true;                                                                                \
 	} break;
 		S3_FOR_EACH_NBF(S3CASE)
-		S3_FOR_EACH_ALT(S3CASE)
 #undef S3CASE
 	default: return fail(SGX_EINVAL, "score3: %d B fragments not supported", NBF);
 	}
 	HIPCHK(hipGetLastError());
-	if (t3_after) { rc = launch_t3(); if (rc) return rc; }
 	{
-		const int per = NCW * NAFW * ((NBF + NCBW - 1) / NCBW) * 256;
+		const int per = NCW * NAFW * NBF * 256;
 		hipLaunchKernelGGL(s3_reduce_kernel, dim3((unsigned)((per / 4 + 255) / 256), (unsigned)pl.vt), dim3(256), 0, st,
-			pl, (int)M, NCW, NAFW, NBF, NCBW, h->s3_slabs, h->mf_acc, ep.acc_stride, h->counters, h->cur5);
+			pl, (int)M, NCW, NAFW, NBF, 1, h->s3_slabs, h->mf_acc, ep.acc_stride, h->counters, h->cur5);
 	}
-	HIPCHK(hipStreamWaitEvent(st, h->s3_join, 0));
 	const int btop = md.quant ? 0 : (int)(2 * M);
 	switch (md.K) {
 #define ECASE(KK) case KK:                                                                     \
 	hipLaunchKernelGGL((score3_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, md, ep, h->mf_acc, \
-		h->s3_t3 + (size_t)S3_NR * M * md.P * 2, b->n3, b->ovf, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid); \
+		h->s3_t3 + (size_t)b->nr * M * md.P * 2, b->n3, b->ovf, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid); \
 	hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, 256>), dim3((unsigned)std::min<size_t>(M, 4 * (size_t)h->n_cu)), dim3(256), 0, st, \
-		RowsRef{b->tiles, 0, b->ntile, b->cptr, b->cidx, b->corient}, (int)M, md, h->recs, h->counters, out8, valid, (const int *)h->s3_ovf, 23, btop, h->fb_spa2, h->fb_x2); \
+		rr, (int)M, md, h->recs, h->counters, out8, valid, (const int *)h->s3_ovf, 23, btop, h->fb_spa2, h->fb_x2); \
 	break;
 	FOR_EACH_K(ECASE)
 #undef ECASE
@@ -1202,9 +1239,12 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[1], st));
 	h->stats.score_launches = 6;
-	rc = launch_spa<IN_2BIT>(h, RowsRef{b->tiles, 0, b->ntile, b->cptr, b->cidx, b->corient}, M, out8, lazy_dense);
+	rc = launch_spa<IN_2BIT>(h, rr, M, out8, lazy_dense);
 	if (rc) return rc;
+	if (lazy_dense) h->pend_dense.blk = b;
 	HIPCHK(hipEventRecord(h->ev[2], st));
+	HIPCHK(hipEventRecord(b->last_read, st));
+	const_cast<sgx_block *>(b)->was_read = true;
 	HIPCHK(hipMemcpyAsync(h->h_counters, h->counters, 24 * sizeof(int), hipMemcpyDeviceToHost, st));
 	h->stats.n_variants = M;
 	h->stats_pending = true;
@@ -1235,6 +1275,7 @@ extern "C" int sgx_scan_block(sgx_handle *h, const sgx_block *b, double *out8_de
 {
 	if (!h || !b) return fail(SGX_EINVAL, "sgx_scan_block: NULL argument");
 	if (!out8_dev || !valid_dev) return fail(SGX_EINVAL, "sgx_scan_block: NULL buffer");
+	if (b->lists_only) return fail(SGX_EINVAL, "sgx_scan_block: not a resident block");
 	if (b->M == 0) return SGX_OK;
 	if (b->device != h->device) return fail(SGX_EINVAL, "sgx_scan_block: block and handle are on different devices");
 	if (b->N != h->md.N) return fail(SGX_EINVAL, "sgx_scan_block: the block holds rows of %d samples, the model has %d", b->N, h->md.N);
@@ -1246,10 +1287,12 @@ extern "C" int sgx_scan_block(sgx_handle *h, const sgx_block *b, double *out8_de
 	if (!h->mf_ok || h->force_v1) {
 		// FP64 kernels on the tiled rows (test hook; models outside the fixed-point form's range)
 		hipStream_t st = lane->stream;
+		HIPCHK(hipStreamWaitEvent(st, b->ready, 0));
 		HIPCHK(hipMemsetAsync(lane->counters, 0, 24 * sizeof(int), st));
 		if (lane->cur5) HIPCHK(hipMemsetAsync(lane->cur5, 0, 8 * sizeof(int), st));
 		HIPCHK(hipEventRecord(lane->ev[0], st));
-		const RowsRef rr{b->tiles, 0, b->ntile};
+		RowsRef rr = block_rows(b);
+		rr.cptr = nullptr; rr.cidx = nullptr; rr.corient = nullptr;
 		switch (lane->md.K) {
 #define VCASE(KK) case KK: hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, 256>), dim3((unsigned)b->M), dim3(256), 0, st, rr, (int)b->M, lane->md, \
 	lane->recs, lane->counters, out8_dev, valid_dev, (const int *)nullptr, 0, 0, (int *)nullptr, (int *)nullptr); break;
@@ -1262,6 +1305,8 @@ extern "C" int sgx_scan_block(sgx_handle *h, const sgx_block *b, double *out8_de
 		rc = launch_spa<IN_2BIT>(lane, rr, b->M, out8_dev);
 		if (rc) return rc;
 		HIPCHK(hipEventRecord(lane->ev[2], st));
+		HIPCHK(hipEventRecord(b->last_read, st));
+		const_cast<sgx_block *>(b)->was_read = true;
 		HIPCHK(hipMemcpyAsync(lane->h_counters, lane->counters, 24 * sizeof(int), hipMemcpyDeviceToHost, st));
 		lane->stats.n_variants = b->M;
 		lane->stats_pending = true;
@@ -1270,14 +1315,28 @@ extern "C" int sgx_scan_block(sgx_handle *h, const sgx_block *b, double *out8_de
 	return launch_block_scan(lane, b, b->M, out8_dev, valid_dev, true);
 }
 
-// a scratch block of this lane for calls that bring row-major rows
+// the lists of this lane's row-major calls (the rows stay where the caller has them)
 static int ensure_tmp_block(sgx_handle *lane, int which, size_t M)
 {
 	sgx_block *&tb = lane->tmp_blk[which];
 	if (tb && tb->cap >= M) return SGX_OK;
 	HIPCHK(hipStreamSynchronize(lane->stream));
 	if (tb) { sgx_block_free(tb); tb = nullptr; }
-	return sgx_block_create(lane->md.N, M, lane->device, &tb);
+	return block_create(lane->md.N, M, lane->device, true, 0, &tb);
+}
+
+// row-major rows on the device -> table: one pass over the rows for the lists of the missing genotypes, then the
+// scan reads the rows where they are
+static int scan_rows_dev(sgx_handle *lane, int which, const uint8_t *rows_dev, size_t bpv, size_t M, double *out8, uint8_t *valid, bool lazy_dense)
+{
+	int rc = ensure_tmp_block(lane, which, M);
+	if (rc) return rc;
+	sgx_block *tb = lane->tmp_blk[which];
+	tb->ext_rows = rows_dev; tb->ext_bpv = bpv;
+	rc = block_put_rows(tb, rows_dev, bpv, 0, M, lane->stream);
+	if (!rc) rc = block_finish(tb, M, lane->stream);
+	if (rc) return rc;
+	return launch_block_scan(lane, tb, M, out8, valid, lazy_dense);
 }
 
 extern "C" int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev, size_t bpv,
@@ -1299,13 +1358,7 @@ extern "C" int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev, size_
 	rc = next_lane(h, M, &lane);
 	if (rc) return rc;
 	if (!h->mf_ok || h->force_v1) return launch_scan<IN_2BIT>(lane, packed_dev, bpv, M, out8_dev, valid_dev);
-	// the rows into this lane's scratch block, then the block scan
-	rc = ensure_tmp_block(lane, 0, M);
-	if (rc) return rc;
-	rc = block_put_rows(lane->tmp_blk[0], packed_dev, bpv, 0, M, lane->stream);
-	if (!rc) rc = block_finish(lane->tmp_blk[0], M, lane->stream);
-	if (rc) return rc;
-	return launch_block_scan(lane, lane->tmp_blk[0], M, out8_dev, valid_dev, true);
+	return scan_rows_dev(lane, 0, packed_dev, bpv, M, out8_dev, valid_dev, true);
 }
 
 static const size_t STAGE_BYTES = (size_t)1 << 30;    // burden rows are made and scanned in chunks of this size
@@ -1343,6 +1396,7 @@ static int ensure_pipe(sgx_handle *h, size_t in_bytes, size_t pk_bytes, size_t M
 	if (!h->cstream) {
 		HIPCHK(hipStreamCreateWithFlags(&h->cstream, hipStreamNonBlocking));
 		HIPCHK(hipEventCreateWithFlags(&h->ev_h2d, hipEventDisableTiming));
+		for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&h->ev_copy[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&h->ev_done[k], hipEventDisableTiming)); }
 		HIPCHK(hipMalloc((void **)&h->pipe_flag, sizeof(int)));
 		HIPCHK(hipHostMalloc((void **)&h->h_pipe_flag, sizeof(int), hipHostMallocDefault));
 	}
@@ -1402,7 +1456,7 @@ static int scan_host(sgx_handle *h, const void *rows, size_t src_row_bytes, size
 	if (rc) return rc;
 	rc = ensure_recs(h, chunk);
 	if (rc) return rc;
-	// 2-bit rows (as they come, or packed from hard calls) go through a scratch block per pipeline buffer
+	// 2-bit rows (as they come, or packed from hard calls) take the MFMA path, the lists of a chunk per pipeline buffer
 	const bool blocks = (INPUT == IN_2BIT || can_pack) && h->mf_ok && !h->force_v1;
 	if (blocks) for (int b = 0; b < 2; b++) { rc = ensure_tmp_block(h, b, chunk); if (rc) return rc; }
 	sgx_stats total{};
@@ -1462,13 +1516,8 @@ static int scan_host(sgx_handle *h, const void *rows, size_t src_row_bytes, size
 		// the COMPUTE stream: on the copy stream the 2.5 ms of ingest sat between two 9.5-ms copies and the
 		// link idled a fifth of the time (43 GB/s; the next copy now starts as this one ends).
 		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_h2d, 0));
-		if (as_block) {
-			const uint8_t *r2 = INPUT == IN_2BIT ? h->pipe_in[b] : h->pipe_pk[b];
-			rc = block_put_rows(h->tmp_blk[b], r2, INPUT == IN_2BIT ? dev_row_bytes : pk_row, 0, m, h->stream);
-			if (!rc) rc = block_finish(h->tmp_blk[b], m, h->stream);
-			if (rc) return rc;
-		}
-		if (as_block) rc = launch_block_scan(h, h->tmp_blk[b], m, h->pipe_out[b], h->pipe_valid[b]);
+		if (as_block) rc = scan_rows_dev(h, b, INPUT == IN_2BIT ? h->pipe_in[b] : h->pipe_pk[b], INPUT == IN_2BIT ? dev_row_bytes : pk_row, m,
+			h->pipe_out[b], h->pipe_valid[b], false);
 		else if (INPUT == IN_2BIT) rc = launch_scan<IN_2BIT>(h, h->pipe_in[b], dev_row_bytes, m, h->pipe_out[b], h->pipe_valid[b]);
 		else if (packed_ok) rc = launch_scan<IN_2BIT>(h, h->pipe_pk[b], pk_row, m, h->pipe_out[b], h->pipe_valid[b]);
 		else if (INPUT == IN_U8) rc = launch_scan<IN_U8>(h, h->pipe_in[b], dev_row_bytes, m, h->pipe_out[b], h->pipe_valid[b]);
@@ -1509,6 +1558,7 @@ extern "C" int sgx_block_load(sgx_handle *h, sgx_block *b, const uint8_t *packed
 {
 	if (!h || !b) return fail(SGX_EINVAL, "sgx_block_load: NULL argument");
 	if (!packed) return fail(SGX_EINVAL, "sgx_block_load: NULL buffer");
+	if (b->lists_only) return fail(SGX_EINVAL, "sgx_block_load: not a resident block");
 	if (b->device != h->device) return fail(SGX_EINVAL, "sgx_block_load: block and handle are on different devices");
 	if (M == 0 || M > b->cap) return fail(SGX_EINVAL, "sgx_block_load: %zu variants, the block holds up to %zu", M, b->cap);
 	if (bpv < (size_t)(b->N + 3) / 4)
@@ -1520,13 +1570,13 @@ extern "C" int sgx_block_load(sgx_handle *h, sgx_block *b, const uint8_t *packed
 	chunk = std::min(chunk, (M + 15) & ~(size_t)15);
 	rc = ensure_pipe(h, chunk * dev_row, 0, 1);
 	if (rc) return rc;
-	hipEvent_t ev_copy[2], ev_done[2];
-	for (int k = 0; k < 2; k++) { HIPCHK(hipEventCreateWithFlags(&ev_copy[k], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_done[k], hipEventDisableTiming)); }
+	rc = block_begin_load(h, b, h->stream);
+	if (rc) return rc;
 	int i = 0;
 	for (size_t off = 0; off < M; off += chunk, i++) {
 		const size_t m = std::min(chunk, M - off);
 		const int k = i & 1;
-		if (i >= 2) HIPCHK(hipStreamWaitEvent(h->cstream, ev_done[k], 0));      // the buffer's previous chunk has been rearranged
+		if (i >= 2) HIPCHK(hipStreamWaitEvent(h->cstream, h->ev_done[k], 0));      // the buffer's previous chunk has been read
 		const uint8_t *src = packed + off * bpv;
 		if (bpv == dev_row) {
 			HIPCHK(hipMemcpyAsync(h->pipe_in[k], src, m * dev_row, hipMemcpyHostToDevice, h->cstream));
@@ -1534,17 +1584,16 @@ extern "C" int sgx_block_load(sgx_handle *h, sgx_block *b, const uint8_t *packed
 			if (dev_row > bpv) HIPCHK(hipMemsetAsync(h->pipe_in[k], 0, m * dev_row, h->cstream));
 			HIPCHK(hipMemcpy2DAsync(h->pipe_in[k], dev_row, src, bpv, std::min(bpv, dev_row), m, hipMemcpyHostToDevice, h->cstream));
 		}
-		HIPCHK(hipEventRecord(ev_copy[k], h->cstream));
-		HIPCHK(hipStreamWaitEvent(h->stream, ev_copy[k], 0));
+		HIPCHK(hipEventRecord(h->ev_copy[k], h->cstream));
+		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_copy[k], 0));
 		rc = block_put_rows(b, h->pipe_in[k], dev_row, off, m, h->stream);
 		if (rc) return rc;
-		HIPCHK(hipEventRecord(ev_done[k], h->stream));
+		HIPCHK(hipEventRecord(h->ev_done[k], h->stream));
 	}
 	rc = block_finish(b, M, h->stream);
 	if (rc) return rc;
 	HIPCHK(hipStreamSynchronize(h->cstream));      // the caller's buffer is free
 	HIPCHK(hipStreamSynchronize(h->stream));
-	for (int k = 0; k < 2; k++) { (void)hipEventDestroy(ev_copy[k]); (void)hipEventDestroy(ev_done[k]); }
 	return SGX_OK;
 }
 

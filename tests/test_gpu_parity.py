@@ -332,30 +332,77 @@ def test_fallback_paths_give_identical_rows(option, value, counter):
     np.testing.assert_allclose(out[v][:, 3:7], base[v][:, 3:7], rtol=1e-11)
 
 
-def test_block_carrier_lists_equal_row_scans(monkeypatch):
-    """Genotype blocks list the carriers of the rare variants (both orientations: 10 % of the synthetic variants
-    have the alt allele as the major one); the per-variant SPA kernels walk those lists.  Same rows when the
-    lists are ignored ("spa_abl" 512: every variant scans its row), when the block's list is too small for all
-    of them (SAIGEHIP_CLIST_CAP: the later variants go unlisted), and through the exact sweeps."""
+def _scan_block(sc, blk, m):
+    """scan of a loaded block into fresh device buffers -> (out, valid) as numpy"""
+    import torch
+    dev = torch.device("cuda", 0)
+    out = torch.full((m, 8), -1.0, dtype=torch.float64, device=dev)
+    valid = torch.zeros(m, dtype=torch.uint8, device=dev)
+    sc.scan_block(blk, out.data_ptr(), valid.data_ptr())
+    sc.sync()
+    return out.cpu().numpy(), valid.cpu().numpy()
+
+
+def test_block_carrier_lists_equal_row_scans():
+    """Resident genotype blocks list the carriers of the rare variants (both orientations: 10 % of the synthetic
+    variants have the alt allele as the major one); the per-variant SPA kernels walk those lists.  Same rows when
+    the lists are ignored ("spa_abl" 512: every variant scans its row), from the row-major call (which never has
+    lists), when the block's list is too small for all of them (clist_avg: the later variants go unlisted), and
+    through the exact sweeps."""
+    from saigegds_amd._lib import Block
     sm, packed = _synthetic_case(3001, 1200, "binary", 0.05, seed=29)
     ref, ref_valid = _oracle(sm).scan_2bit(packed)
     v = ref_valid.astype(bool)
-    with _scanner(sm) as sc:
-        base, valid = sc.scan_2bit(packed)
+    with _scanner(sm) as sc, Block(sm.n, 1200) as blk:
+        sc.load_block(blk, packed)
+        assert blk.n_variants == 1200
+        base, valid = _scan_block(sc, blk, 1200)
         assert sc.stats()["n_spa"] > 30
         assert_table_close(base, valid, ref, ref_valid, what="carrier lists")
         sc.set_option("spa_abl", 512)
-        rows, _ = sc.scan_2bit(packed)
+        rows, _ = _scan_block(sc, blk, 1200)
         np.testing.assert_allclose(rows[v][:, 3:7], base[v][:, 3:7], rtol=1e-11)
         sc.set_option("spa_abl", 0)
+        direct, valid = sc.scan_2bit(packed)
+        assert_table_close(direct, valid, ref, ref_valid, what="row-major call")
+        np.testing.assert_allclose(direct[v][:, 3:7], base[v][:, 3:7], rtol=1e-11)
+        assert np.array_equal(direct[v][:, :3], base[v][:, :3])
         sc.set_option("spa_exact", 1)
-        exact, valid = sc.scan_2bit(packed)
+        exact, valid = _scan_block(sc, blk, 1200)
         assert_table_close(exact, valid, ref, ref_valid, what="carrier lists, exact sweeps")
-    monkeypatch.setenv("SAIGEHIP_CLIST_CAP", "40")     # 48 000 entries for 1 200 variants with ~300 carriers each
-    with _scanner(sm) as sc:
-        part, valid = sc.scan_2bit(packed)
+        sc.set_option("spa_exact", 0)
+        with Block(sm.n, 1200, clist_avg=40) as small:      # 48 000 entries for 1 200 variants with ~300 carriers each
+            sc.load_block(small, packed)
+            part, valid = _scan_block(sc, small, 1200)
     assert_table_close(part, valid, ref, ref_valid, what="carrier lists, full list")
     np.testing.assert_allclose(part[v][:, 3:7], base[v][:, 3:7], rtol=1e-11)
+
+
+def test_block_reload_without_sync_waits_for_its_readers():
+    """Two lanes: a block is scanned and reloaded with other rows right away, no sync in between -- the load has
+    to wait for the scan that still reads the block (and for a deferred dense pass that points at it); both
+    tables must be their own rows' tables."""
+    import torch
+    from saigegds_amd._lib import Block
+    sm, packed = _synthetic_case(3001, 1600, "binary", 0.05, seed=41)
+    ref, ref_valid = _oracle(sm).scan_2bit(packed)
+    dev = torch.device("cuda", 0)
+    with _scanner(sm) as sc, Block(sm.n, 800) as blk:
+        sc.set_option("lanes", 2)
+        sc.set_option("force_dense", 1)               # every flagged variant onto the deferred dense pass
+        bpv = sc.row_stride()
+        pk = torch.zeros((2, 800, bpv), dtype=torch.uint8, device=dev)
+        pk[:, :, :packed.shape[1]] = torch.from_numpy(packed.reshape(2, 800, -1)).to(dev)
+        out = torch.full((2, 800, 8), -1.0, dtype=torch.float64, device=dev)
+        valid = torch.zeros((2, 800), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        for rep in range(3):
+            for half in range(2):
+                sc.load_block_dev(blk, pk[half].data_ptr(), bpv, 800)
+                sc.scan_block(blk, out[half].data_ptr(), valid[half].data_ptr())
+        sc.sync()
+        got, gv = out.cpu().numpy().reshape(-1, 8), valid.cpu().numpy().reshape(-1)
+    assert_table_close(got, gv, ref, ref_valid, what="reload without sync")
 
 
 def test_two_lanes_give_identical_tables():

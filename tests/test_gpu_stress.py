@@ -49,42 +49,29 @@ def test_random_small_shapes(seed):
         assert np.array_equal(valid, valid2) and np.array_equal(np.nan_to_num(out, nan=-7), np.nan_to_num(out2, nan=-7)), what
 
 
-_ALT_CHILD = r"""
-import sys, numpy as np
-sys.path.insert(0, {root!r}); sys.path.insert(0, {root!r} + "/tests")
-from test_gpu_stress import _case
-from saigegds_amd._lib import Scanner
-rng = np.random.default_rng(77)
-sm, packed = _case(rng, 3000, 700, 12, "binary", 0.01)
-with Scanner(sm) as sc:
-    limbs, ngroups = sc.score_layout()
-    out, valid = sc.scan_2bit(packed)
-np.savez({out!r}, out=out, valid=valid, ncol=int(sum(limbs)) + 1)
-"""
-
-
-def test_alternative_kernel_forms_give_the_same_table(tmp_path):
-    """The experiment forms of the contraction kernel that DESIGN 6 reports on -- two column groups of the
-    consumer waves at 12 B fragments (SAIGEHIP_S3_ALT=1) and the sparse pass launched after the kernel
-    (SAIGEHIP_T3_ORDER=1) -- are read once per process, so a child process runs the scan with them; the table has
-    to be the default form's bit for bit (integer accumulation) and both within the usual bounds of the oracle."""
-    import subprocess
-    import sys
-    from conftest import ROOT
+def test_twelve_fragments_block_and_rows_give_the_same_table():
+    """K = 12 fills 11 value fragments (+ bit-1 = 12 B fragments of the contraction kernel): the row-major call and
+    a resident block of the same rows give the same table bit for bit (integer accumulation; the SPA stage reads
+    the same rows either way, the block's carrier lists hold the same carriers), both within the usual bounds of
+    the oracle."""
+    import torch
     from oracle import Oracle
-    import os
-    res = {}
-    for tag, env in (("default", {}), ("alt", {"SAIGEHIP_S3_ALT": "1", "SAIGEHIP_T3_ORDER": "1"})):
-        path = str(tmp_path / f"{tag}.npz")
-        e = dict(os.environ); e.update(env)
-        subprocess.run([sys.executable, "-c", _ALT_CHILD.format(root=ROOT, out=path)], check=True, env=e, timeout=240)
-        res[tag] = np.load(path)
-    ncol = int(res["default"]["ncol"])
-    assert 160 < ncol <= 176, f"the case is meant to fill 11 value fragments (+ bit-1 = 12): {ncol} limb columns"
-    a, b = res["default"], res["alt"]
-    assert np.array_equal(a["valid"], b["valid"])
-    assert np.array_equal(np.nan_to_num(a["out"], nan=-7), np.nan_to_num(b["out"], nan=-7))
+    from saigegds_amd._lib import Block, Scanner
     rng = np.random.default_rng(77)
     sm, packed = _case(rng, 3000, 700, 12, "binary", 0.01)
     ref, ref_valid = Oracle(sm).scan_2bit(packed)
-    assert_table_close(b["out"], b["valid"], ref, ref_valid, quant=False, what="alternative forms, K = 12")
+    dev = torch.device("cuda", 0)
+    with Scanner(sm) as sc, Block(sm.n, 700) as blk:
+        limbs, ngroups = sc.score_layout()
+        ncol = int(sum(limbs)) + 1
+        assert 160 < ncol <= 176, f"the case is meant to fill 11 value fragments (+ bit-1 = 12): {ncol} limb columns"
+        out, valid = sc.scan_2bit(packed)
+        sc.load_block(blk, packed)
+        o2 = torch.full((700, 8), -1.0, dtype=torch.float64, device=dev)
+        v2 = torch.zeros(700, dtype=torch.uint8, device=dev)
+        sc.set_option("spa_abl", 512)            # the SPA kernels scan the rows, as the row-major call does
+        sc.scan_block(blk, o2.data_ptr(), v2.data_ptr())
+        sc.sync()
+    assert np.array_equal(valid, v2.cpu().numpy())
+    assert np.array_equal(np.nan_to_num(out, nan=-7), np.nan_to_num(o2.cpu().numpy(), nan=-7))
+    assert_table_close(out, valid, ref, ref_valid, quant=False, what="K = 12")

@@ -14,6 +14,7 @@
 
 #define S3_KERNEL_ONLY
 #include "../saigegds_amd/csrc/kern_score3.h"
+#include "../saigegds_amd/csrc/kern_lists.h"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -36,18 +37,19 @@ __global__ void fill_codes(uint32_t *dst, size_t ndw, uint64_t seed)
 
 struct Shape { int N; size_t M; };
 
-template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int ABL, int NCB = 1, int NBUF = 2>
+template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int ABL, int NCB = 1, int NBUF = 2, int RM = 0>
 static float run(const char *name, const uint8_t *A, const uint8_t *Fl, int ntile, size_t M, int wg_per_cu, int n_cu, int *out, size_t out_ints,
-	int reps, S3Plan *plan_out = nullptr)
+	int reps, S3Plan *plan_out = nullptr, size_t bpv = 0)
 {
 	const int grid = n_cu * wg_per_cu;
 	constexpr int NCV = WAVES / NCB, NBW = (NBF + NCB - 1) / NCB;
-	const S3Plan pl = s3_plan(M, ntile, grid, NAF * NCV);
+	const S3Plan pl = s3_plan(M, ntile, grid, NAF * NCV, bpv);
 	const size_t need = (size_t)pl.ng * pl.ipg * WAVES * NAF * NBW * 256;
 	if (need > out_ints) { fprintf(stderr, "%s: out buffer too small (%zu > %zu)\n", name, need, out_ints); exit(1); }
 	if (plan_out) *plan_out = pl;
-	const size_t lds = ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * NCV * NAF) * 1024;
-	auto kern = score3_kernel<NBF, NAF, WAVES, NLA, NLB, DA, DB, ABL, NCB, NBUF>;
+	const size_t lds = ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * NCV * NAF * (RM == 1 ? 2 : 1)) * 1024;
+	if (lds > 163840) { printf("%-40s skipped: %zu B of LDS\n", name, lds); return 0; }
+	auto kern = score3_kernel<NBF, NAF, WAVES, NLA, NLB, DA, DB, ABL, NCB, NBUF, RM>;
 	static unsigned long long *stamps = nullptr;
 	if (!stamps) CK(hipMalloc((void **)&stamps, 16 * 4096));
 	CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -76,8 +78,8 @@ static float run(const char *name, const uint8_t *A, const uint8_t *Fl, int ntil
 			std::sort(c.begin(), c.end());
 			if (!c.empty()) ghz = c[c.size() / 2];
 		}
-		printf("%-40s NBF=%2d NAF=%d NC=%d/%d NL=%d+%d D=%d/%d buf %d ABL=%2d  items/grp=%4d f=%2d  %7.3f ms  %6.0f GB/s  %.3f of 8 TB/s",
-			name, NBF, NAF, WAVES, NCB, NLA, NLB, DA, DB, NBUF, ABL, pl.ipg, pl.f, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0);
+		printf("%-40s %s NBF=%2d NAF=%d NC=%d/%d NL=%d+%d D=%d/%d buf %d ABL=%2d  items/grp=%4d f=%2d  %7.3f ms  %6.0f GB/s  %.3f of 8 TB/s",
+			name, RM == 2 ? "lines" : RM ? "rows " : "tiles", NBF, NAF, WAVES, NCB, NLA, NLB, DA, DB, NBUF, ABL, pl.ipg, pl.f, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0);
 		if (ABL & 16) printf("  clock %.3f GHz", ghz);
 		printf("\n");
 		fflush(stdout);
@@ -86,8 +88,8 @@ static float run(const char *name, const uint8_t *A, const uint8_t *Fl, int ntil
 }
 
 // CPU check: sums of the item slabs per (variant, column) against the direct sum
-template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int NCB = 1, int NBUF = 2>
-static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu)
+template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int NCB = 1, int NBUF = 2, int RM = 0>
+static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu, size_t row_pad = 0)
 {
 	const int ntile = 2 * ((N + 511) / 512);
 	const size_t nfrag = (M + 15) / 16, abytes = nfrag * (size_t)ntile * 1024;
@@ -119,8 +121,21 @@ static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu)
 			memcpy(&hA[s3_piece_off(v, p, ntile)], w, 16);
 		}
 	uint8_t *dA, *dF; int *dO;
-	CK(hipMalloc((void **)&dA, abytes)); CK(hipMalloc((void **)&dF, flbytes));
-	CK(hipMemcpy(dA, hA.data(), abytes, hipMemcpyHostToDevice));
+	// row-major form: exactly M rows (no padding rows: a read past the last row would fault or show)
+	const size_t bpv = (size_t)ntile * 64 + row_pad;
+	if (RM) {
+		hA.assign(M * bpv, 0xFF);                      // (the bytes between the rows hold missing codes: never read)
+		for (size_t v = 0; v < M; v++)
+			for (size_t p = 0; p < (size_t)ntile * 4; p++) {
+				uint32_t w[4] = {0, 0, 0, 0};
+				for (int u = 0; u < 4; u++)
+					for (int e = 0; e < 16; e++) w[u] |= (uint32_t)code[v * ntile * 256 + p * 64 + u * 16 + e] << (2 * e);
+				memcpy(&hA[v * bpv + p * 16], w, 16);
+			}
+	}
+	const size_t abytes_dev = RM ? M * bpv : abytes;
+	CK(hipMalloc((void **)&dA, abytes_dev)); CK(hipMalloc((void **)&dF, flbytes));
+	CK(hipMemcpy(dA, hA.data(), abytes_dev, hipMemcpyHostToDevice));
 	CK(hipMemcpy(dF, hF.data(), flbytes, hipMemcpyHostToDevice));
 	const int grid = n_cu * wg_per_cu;
 	constexpr int NCV = WAVES / NCB, NBW = (NBF + NCB - 1) / NCB;
@@ -129,7 +144,7 @@ static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu)
 	CK(hipMalloc((void **)&dO, oints * 4));
 	CK(hipMemset(dO, 0xCD, oints * 4));
 	S3Plan pl;
-	run<NBF, NAF, WAVES, NLA, NLB, DA, DB, 0, NCB, NBUF>(name, dA, dF, ntile, M, wg_per_cu, n_cu, dO, oints, 0, &pl);
+	run<NBF, NAF, WAVES, NLA, NLB, DA, DB, 0, NCB, NBUF, RM>(name, dA, dF, ntile, M, wg_per_cu, n_cu, dO, oints, 0, &pl, bpv);
 	std::vector<int> hO(oints);
 	CK(hipMemcpy(hO.data(), dO, oints * 4, hipMemcpyDeviceToHost));
 	long long bad = 0;
@@ -154,9 +169,72 @@ static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu)
 			if (got != ref) { if (bad < 5) fprintf(stderr, "%s: variant %zu col %d: got %lld want %lld\n", name, v, c, got, ref); bad++; }
 		}
 	}
-	printf("check %-30s N=%d M=%zu ntile=%d ng=%d wpg=%d rf=%d rem=%d f=%d: %s\n", name, N, M, ntile, pl.ng, pl.wpg, pl.rf, pl.rem, pl.f, bad ? "FAILED" : "ok");
+	printf("check %s %-30s N=%d M=%zu ntile=%d ng=%d wpg=%d rf=%d rem=%d f=%d: %s\n", RM ? "rows " : "tiles", name, N, M, ntile, pl.ng, pl.wpg, pl.rf, pl.rem, pl.f, bad ? "FAILED" : "ok");
 	CK(hipFree(dA)); CK(hipFree(dF)); CK(hipFree(dO));
 	return bad ? 1 : 0;
+}
+
+// the one-pass list builder (kern_lists.h) on row-major rows: timing, and the lists against a CPU walk
+static int lists_bench(const uint8_t *rows, size_t bpv, int N, size_t M, int ntile, int reps, bool verify)
+{
+	S3Lists L{};
+	const size_t cap = std::max<size_t>(M * std::max<size_t>(64, (size_t)N / 128), (size_t)S3_NSUB * 256);
+	L.idx_cap = (unsigned)cap; L.ld = M; L.nr = s3_nranges(ntile); L.nsub = (int)std::max<size_t>(1, std::min<size_t>(S3_NSUB, (M * (size_t)L.nr + 3) / 4));
+	CK(hipMalloc((void **)&L.idx, cap * 4));
+	CK(hipMalloc((void **)&L.cursor, S3_NSUB * S3_CURSOR_STRIDE * 4));
+	CK(hipMalloc((void **)&L.lstart, S3_NR * M * 4)); CK(hipMalloc((void **)&L.lcnt, S3_NR * M * 4));
+	CK(hipMalloc((void **)&L.nzp, S3_NR * M * 4)); CK(hipMalloc((void **)&L.n2p, S3_NR * M * 4));
+	uint8_t *copy = nullptr;
+	CK(hipMalloc((void **)&copy, M * bpv));
+	hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+	const unsigned grid = (unsigned)((M * (size_t)L.nr + 3) / 4);
+	for (int mode = 0; mode < 2; mode++) {
+		float best = 1e30f;
+		for (int r = 0; r < reps + 1; r++) {
+			CK(hipMemset(L.cursor, 0, S3_NSUB * S3_CURSOR_STRIDE * 4));
+			CK(hipEventRecord(a, 0));
+			if (mode == 0) hipLaunchKernelGGL((s3_lists_kernel<8, false, false>), dim3(grid), dim3(256), 0, 0, rows, bpv, N, (int)M, 0, ntile, L, (uint8_t *)nullptr, (size_t)0);
+			else hipLaunchKernelGGL((s3_lists_kernel<8, true, true>), dim3(grid), dim3(256), 0, 0, rows, bpv, N, (int)M, 0, ntile, L, copy, bpv);
+			CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); CK(hipGetLastError());
+			float ms; CK(hipEventElapsedTime(&ms, a, b));
+			if (r > 0 || reps == 0) best = std::min(best, ms);
+		}
+		unsigned long long used = 0;
+		{ std::vector<unsigned> hc(S3_NSUB * S3_CURSOR_STRIDE); CK(hipMemcpy(hc.data(), L.cursor, hc.size() * 4, hipMemcpyDeviceToHost)); for (int q = 0; q < S3_NSUB; q++) used += hc[q * S3_CURSOR_STRIDE]; }
+		printf("lists kernel %-14s N=%d M=%zu: %7.3f ms  %6.0f GB/s read  (%llu entries listed, pool %zu)\n", mode ? "(+ copy)" : "(lists only)",
+			N, M, best, (double)M * ntile * 64 / best / 1e6, used, cap);
+	}
+	int bad = 0;
+	if (verify) {
+		std::vector<uint8_t> hr(M * bpv), hc(M * bpv);
+		CK(hipMemcpy(hr.data(), rows, M * bpv, hipMemcpyDeviceToHost));
+		CK(hipMemcpy(hc.data(), copy, M * bpv, hipMemcpyDeviceToHost));
+		std::vector<unsigned> st((size_t)L.nr * M), idx(cap); std::vector<int> cn((size_t)L.nr * M), nz((size_t)L.nr * M), n2((size_t)L.nr * M);
+		CK(hipMemcpy(st.data(), L.lstart, st.size() * 4, hipMemcpyDeviceToHost));
+		CK(hipMemcpy(cn.data(), L.lcnt, cn.size() * 4, hipMemcpyDeviceToHost));
+		CK(hipMemcpy(nz.data(), L.nzp, nz.size() * 4, hipMemcpyDeviceToHost));
+		CK(hipMemcpy(n2.data(), L.n2p, n2.size() * 4, hipMemcpyDeviceToHost));
+		CK(hipMemcpy(idx.data(), L.idx, cap * 4, hipMemcpyDeviceToHost));
+		for (size_t v = 0; v < M && bad < 5; v++) {
+			if (memcmp(&hr[v * bpv], &hc[v * bpv], (size_t)ntile * 64)) { fprintf(stderr, "lists: copy of row %zu differs\n", v); bad++; }
+			for (int g = 0; g < L.nr; g++) {
+				std::vector<unsigned> want; int wz = 0, w2 = 0;
+				const int s0 = s3_range_t0(g, ntile, L.nr) * 256, s1 = std::min(N, s3_range_t0(g + 1, ntile, L.nr) * 256);
+				for (int s = s0; s < s1; s++) {
+					const int c = (hr[v * bpv + s / 4] >> (2 * (s % 4))) & 3;
+					if (c == 3) want.push_back((unsigned)s);
+					wz += c != 0; w2 += c == 2;
+				}
+				const size_t e = (size_t)g * M + v;
+				bool ok = cn[e] == (int)want.size() && nz[e] == wz && n2[e] == w2;
+				if (ok) { std::vector<unsigned> got(idx.begin() + st[e], idx.begin() + st[e] + want.size()); std::sort(got.begin(), got.end()); ok = got == want; }
+				if (!ok) { fprintf(stderr, "lists: variant %zu range %d: count %d want %zu, nz %d want %d, n2 %d want %d\n", v, g, cn[e], want.size(), nz[e], wz, n2[e], w2); bad++; }
+			}
+		}
+		printf("lists check N=%d M=%zu: %s\n", N, M, bad ? "FAILED" : "ok");
+	}
+	CK(hipFree(L.idx)); CK(hipFree(L.cursor)); CK(hipFree(L.lstart)); CK(hipFree(L.lcnt)); CK(hipFree(L.nzp)); CK(hipFree(L.n2p)); CK(hipFree(copy));
+	return bad;
 }
 
 int main(int argc, char **argv)
@@ -165,6 +243,7 @@ int main(int argc, char **argv)
 	const int n_cu = pr.multiProcessorCount;
 	if (argc > 1 && !strcmp(argv[1], "check")) {
 		int bad = 0;
+#ifndef S3_BENCH_SMALL
 		// grids far smaller than the chip so that rounds, leftovers and pieces all occur
 		bad += check<4, 4, 8, 3, 1, 2, 2>("k3 naf4 d2", 5000, 700, 1, 8);
 		bad += check<4, 4, 8, 3, 1, 3, 1>("k3 naf4 big grid", 3000, 300, 1, n_cu);
@@ -193,6 +272,23 @@ int main(int argc, char **argv)
 		bad += check<11, 4, 4, 2, 2, 3, 1, 1, 3>("k13 nbf11 naf4 3 buffers", 1500, 500, 1, 8);
 		bad += check<13, 3, 4, 2, 2, 3, 1, 1, 5>("k16 nbf13 naf3 5 buffers", 1500, 500, 1, 8);
 		bad += check<6, 3, 8, 3, 1, 3, 1, 1, 3>("k5 nbf6 naf3 3 buffers", 2100, 900, 1, 8);
+#endif
+		// row-major rows (the caller's layout, no tiles): M not a multiple of 16, strides beyond the row
+		bad += check<4, 4, 8, 3, 1, 1, 1, 1, 2, 1>("k3 naf4 d1/1", 5000, 700, 1, 8);
+		bad += check<4, 3, 8, 3, 1, 1, 2, 1, 2, 1>("k3 naf3 d1/2, M = 693, stride + 64", 5000, 693, 1, 8, 64);
+		bad += check<4, 4, 8, 3, 1, 1, 1, 1, 2, 1>("k3 naf4 big grid", 3000, 301, 1, n_cu, 16);
+		bad += check<4, 2, 8, 2, 2, 2, 2, 1, 2, 1>("k3 naf2 d2/2 tiny N", 100, 50, 1, 8);
+		bad += check<4, 4, 8, 2, 2, 1, 1, 1, 2, 1>("k3 naf4 one variant", 700, 1, 1, 8, 128);
+		bad += check<11, 4, 4, 3, 1, 1, 1, 1, 2, 1>("k13 naf4 4+3+1", 2500, 803, 1, 8);
+		bad += check<2, 4, 8, 3, 1, 1, 2, 1, 2, 1>("quant naf4", 2100, 900, 1, 8);
+		bad += check<13, 3, 4, 2, 2, 1, 1, 1, 2, 1>("k16 naf3 4+2+2", 1500, 499, 1, 8, 192);
+		bad += check<4, 4, 8, 3, 1, 1, 1, 1, 2, 1>("k3 naf4 d1/1, long rows", 70000, 100, 1, 8, 128);
+		bad += check<4, 2, 8, 3, 1, 2, 2, 1, 2, 1>("k3 naf2 d2/2, long rows", 70000, 500, 1, 8);
+		bad += check<6, 3, 8, 3, 1, 1, 1, 1, 2, 1>("k5 naf3 d1/1", 9000, 1000, 1, 16);
+		// every form of the product's table (kern_score3.h S3_FOR_EACH_NBF)
+#define CHKP(NBF, NAF, NC, NLA, NLB, DA, DB) bad += check<NBF, NAF, NC, NLA, NLB, DA, DB, 1, 2, 1>("product form", 2100 + 37 * NBF, 600 + NBF, 1, 8, (NBF & 1) * 64);
+		S3_FOR_EACH_NBF(CHKP)
+#undef CHKP
 		return bad ? 1 : 0;
 	}
 	const int N = argc > 1 ? atoi(argv[1]) : 430000;
@@ -213,11 +309,58 @@ int main(int argc, char **argv)
 	CK(hipDeviceSynchronize());
 	printf("N=%d M=%zu ntile=%d rows %.3f GB, %d CUs\n", N, M, ntile, (double)M * ntile * 64 / 1e9, n_cu);
 #define R3(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, NCB, NBUF, name) do { \
-	const size_t lds_ = ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * (NC / NCB) * NAF) * 1024; \
-	if (lds_ > 163840) { printf("%-40s skipped: %zu B of LDS\n", name, lds_); break; } \
+\
 	run<NBF, NAF, NC, NLA, NLB, DA, DB, ABL, NCB, NBUF>(name, A, Fl, ntile, M, 1, n_cu, out, oints, reps); } while (0)
 #define R2(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, NCB, name) R3(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, NCB, 2, name)
 #define R(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, name) R2(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, 1, name)
+	if (getenv("RM")) {
+		// row-major rows against tiles, the product forms of K = 3, quantitative, K = 13; N = 50 000 by the command line
+		const size_t bpv = (size_t)ntile * 64;
+		uint8_t *Ar;
+		CK(hipMalloc((void **)&Ar, M * bpv));
+		fill_codes<<<4096, 256>>>((uint32_t *)Ar, M * bpv / 4, 12345);
+		CK(hipDeviceSynchronize());
+		{
+			// small shapes against a CPU walk (N not a multiple of 64, a long-range shape), then the timing
+			uint8_t *Sm; const int n2 = 5003, nt2 = 2 * ((n2 + 511) / 512); const size_t m2 = 333, bp2 = (size_t)nt2 * 64 + 64;
+			CK(hipMalloc((void **)&Sm, m2 * bp2));
+			fill_codes<<<256, 256>>>((uint32_t *)Sm, m2 * bp2 / 4, 777);
+			CK(hipDeviceSynchronize());
+			int badl = lists_bench(Sm, bp2, n2, m2, nt2, 0, true);
+			CK(hipFree(Sm));
+			const int n3 = 600000, nt3 = 2 * ((n3 + 511) / 512); const size_t m3 = 40, bp3 = (size_t)nt3 * 64;
+			CK(hipMalloc((void **)&Sm, m3 * bp3));
+			fill_codes<<<256, 256>>>((uint32_t *)Sm, m3 * bp3 / 4, 778);
+			CK(hipDeviceSynchronize());
+			badl += lists_bench(Sm, bp3, n3, m3, nt3, 0, true);
+			CK(hipFree(Sm));
+			if (badl) return 1;
+			lists_bench(Ar, bpv, N, M, ntile, reps, false);
+		}
+#define R0(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, name) run<NBF, NAF, NC, NLA, NLB, DA, DB, ABL, 1, 2, 0>(name, A, Fl, ntile, M, 1, n_cu, out, oints, reps)
+#define R1(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, name) run<NBF, NAF, NC, NLA, NLB, DA, DB, ABL, 1, 2, 1>(name, Ar, Fl, ntile, M, 1, n_cu, out, oints, reps, nullptr, bpv)
+		R0(4, 4, 8, 3, 1, 2, 2, 0, "k3 naf4 8+3+1 d2/2");
+		R0(4, 4, 8, 3, 1, 2, 1, 0, "k3 naf4 8+3+1 d2/1");
+		R0(4, 3, 8, 3, 1, 3, 2, 0, "k3 naf3 8+3+1 d3/2");
+		R0(4, 4, 8, 3, 1, 2, 2, 1, "k3 naf4 memory only");
+		R1(4, 4, 8, 3, 1, 1, 1, 0, "k3 naf4 8+3+1 pairs d1/1 (160 KiB)");
+		R1(4, 4, 8, 2, 2, 1, 1, 0, "k3 naf4 8+2+2 pairs d1/1 (160 KiB)");
+		R1(4, 3, 8, 3, 1, 1, 2, 0, "k3 naf3 8+3+1 pairs d1/2");
+		R1(4, 3, 8, 2, 2, 1, 2, 0, "k3 naf3 8+2+2 pairs d1/2");
+		R1(4, 2, 8, 3, 1, 2, 2, 0, "k3 naf2 8+3+1 pairs d2/2");
+		R1(4, 2, 12, 3, 1, 1, 2, 0, "k3 naf2 12+3+1 pairs d1/2");
+		R1(4, 4, 8, 3, 1, 1, 1, 1, "k3 naf4 pairs d1/1 memory only");
+		R1(4, 3, 8, 3, 1, 1, 2, 1, "k3 naf3 pairs d1/2 memory only");
+		R0(2, 4, 8, 3, 1, 3, 2, 0, "quant naf4 8+3+1 d3/2");
+		R1(2, 4, 8, 3, 1, 1, 2, 0, "quant naf4 8+3+1 pairs d1/2");
+		R1(2, 4, 8, 3, 1, 1, 3, 0, "quant naf4 8+3+1 pairs d1/3");
+		R0(12, 3, 4, 2, 2, 3, 1, 0, "k13 nbf12 naf3 4+2+2 d3/1");
+		R1(12, 3, 4, 2, 2, 1, 1, 0, "k13 nbf12 naf3 4+2+2 pairs d1/1");
+		R0(6, 3, 8, 3, 1, 3, 1, 0, "k5 naf3 8+3+1 d3/1");
+		R1(6, 3, 8, 3, 1, 1, 1, 0, "k5 naf3 8+3+1 pairs d1/1");
+		return 0;
+	}
+#ifndef S3_BENCH_SMALL
 	if (getenv("ONLY13")) {
 		R2(12, 6, 4, 2, 2, 3, 1, 0, 2, "k13 nbf12 naf6 2x2");
 		return 0;
@@ -326,5 +469,6 @@ int main(int argc, char **argv)
 	R(11, 4, 4, 2, 2, 3, 1, 6 | 16, "k13 naf4 no DMA");
 	R(13, 3, 4, 2, 2, 3, 1, 0, "k16 naf3 4+2+2 d3/1");
 	// N = 50 000 shape is run by passing N on the command line
+#endif
 	return 0;
 }
