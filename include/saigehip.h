@@ -134,7 +134,7 @@ int sgx_score_layout(sgx_handle *h, int32_t *limbs, int32_t n_limbs, int32_t *n_
 
 /* Scan a block of variants held in HOST memory.  packed: n_variants rows of
  * bytes_per_variant bytes (>= ceil(N/4)).  out8: n_variants*8 doubles.
- * valid: n_variants bytes.  Synchronous. */
+ * valid: n_variants bytes.  Synchronous (chunks cross PCIe while the previous chunk is scanned). */
 int sgx_scan_2bit(sgx_handle *h, const uint8_t *packed, size_t bytes_per_variant,
 	size_t n_variants, double *out8, uint8_t *valid);
 
@@ -143,40 +143,44 @@ int sgx_scan_2bit(sgx_handle *h, const uint8_t *packed, size_t bytes_per_variant
 void *sgx_host_alloc(size_t bytes);
 void  sgx_host_free(void *p);
 
-/* Same, all buffers already resident in this GPU's HBM (device pointers).
+/* Same, all buffers already resident in this GPU's HBM (device pointers): the headline path.
  * packed must be 16-byte aligned and bytes_per_variant a multiple of 64 with
- * bytes_per_variant >= sgx_row_stride(N) = 128*ceil(N/512) (a multiple of 64 that is not one of
- * 128 is accepted and takes a slower load pattern).  Asynchronous on the handle's stream;
- * call sgx_sync() before reading results or stats. */
+ * bytes_per_variant >= sgx_row_stride(N) = 128*ceil(N/512) (rows that start on 128-byte lines are read
+ * as whole lines; a stride that is a multiple of 64 only still works, slower).  The rows are read WHERE
+ * THEY ARE, twice: one pass lists the positions of the missing genotypes (the sparse form of
+ * f64_af_ac_impute's walk, src/vectorization.cpp:186-205), then the contraction kernel streams them;
+ * nothing is copied or rearranged.  Asynchronous on one of the handle's streams: the rows, out8_dev and
+ * valid_dev must stay untouched until sgx_sync(), which is also what makes results and stats readable. */
 int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev,
 	size_t bytes_per_variant, size_t n_variants, double *out8_dev,
 	uint8_t *valid_dev);
 
-/* Genotype blocks: the library's device layout of 2-bit rows -----------------------------------
+/* Genotype blocks: rows resident on the device for any number of scans ------------------------------
  * The reference streams one variant at a time out of the GDS file into its C++ code
- * (R/assoc_single.r:202-209, seqApply).  Here the unit that is brought into HBM and scanned is a
- * BLOCK of variants: on load the rows are rearranged on the device into tiles of 16 variants x 256
- * samples (one contiguous KiB each: what a wavefront of the score kernel reads with one instruction)
- * and the positions of the missing genotypes are listed per variant, as are the carriers (sample and
- * code, ascending) of every variant with at most 8 192 of them in the orientation the scan will use
- * (non-zero codes, or the codes other than 2 where the alt allele is the major one) -- the sparse
- * form of a rare variant that f64_nonzero_index (src/saige_main.cpp) builds per variant in the
- * reference, here built once per block.  A block depends on the number of samples only, so one loaded
- * block can be scanned with any number of models (phenotypes).
- * sgx_scan_2bit / sgx_scan_2bit_dev are this load followed by sgx_scan_block on a scratch block.
+ * (R/assoc_single.r:202-209, seqApply) and finds, per variant and per phenotype, the missing genotypes
+ * (f64_af_ac_impute) and the carriers (f64_nonzero_index, src/vectorization.cpp:209-215).  A BLOCK keeps
+ * up to max_variants rows in HBM together with what does not depend on the model: the rows themselves
+ * (row-major, as they came), the positions of their missing genotypes, and the carrier lists (sample and
+ * code, ascending) of every variant with at most 8 192 carriers in the orientation the scan will use
+ * (non-zero codes, or the codes other than 2 where the alt allele is the major one).  One loaded block
+ * can be scanned with any number of models (phenotypes): each scan then streams the rows once.
  *   sgx_block_create    device storage for up to max_variants rows of n_samp samples
- *   sgx_block_bytes     what that takes (rows + lists: about 1.19 x the packed rows at large N)
+ *   sgx_block_bytes     what that takes (about 1.1 x the packed rows at large N)
  *   sgx_block_load_dev  rows already in this GPU's memory (bytes_per_variant a multiple of 16,
- *                       >= sgx_row_stride(n_samp), 16-byte aligned); asynchronous on the handle's stream
+ *                       >= sgx_row_stride(n_samp), 16-byte aligned); asynchronous on the handle's stream;
+ *                       a load waits for the scans that still read the block
  *   sgx_block_load      rows in host memory (>= ceil(n_samp / 4) bytes each), through the pinned pipeline
  *   sgx_scan_block      the scan; asynchronous like sgx_scan_2bit_dev (same lanes, stats, sgx_sync)
- * Variants with more missing genotypes than the block's lists hold (a list entry per missing
+ *   sgx_block_create_ex test hook: carrier lists with room for clist_avg entries per variant on average
+ * A block must not be freed, and its result buffers not read, before sgx_sync() on every handle that
+ * scanned it.  Variants whose missing genotypes find the block's pool full (a list entry per missing
  * genotype, room for 0.8 % of the block at large N) are scanned by the FP64 kernels instead: same
  * results, slower.  Rare variants beyond a full carrier list (1 536 entries per variant of the block
- * on average) have their rows scanned by the SPA kernels, as row-major input has: same results. */
+ * on average) have their rows scanned by the SPA kernels, as sgx_scan_2bit_dev's rows are: same results. */
 typedef struct sgx_block sgx_block;
 size_t sgx_block_bytes(int32_t n_samp, size_t max_variants);
 int  sgx_block_create(int32_t n_samp, size_t max_variants, int device, sgx_block **out);
+int  sgx_block_create_ex(int32_t n_samp, size_t max_variants, int device, long long clist_avg, sgx_block **out);
 void sgx_block_free(sgx_block *b);
 int  sgx_block_load_dev(sgx_handle *h, sgx_block *b, const uint8_t *packed_dev,
 	size_t bytes_per_variant, size_t n_variants);
@@ -227,14 +231,14 @@ int sgx_decode_dbit2(const uint8_t *alleles, size_t bit0, int32_t n_samp, size_t
 int sgx_geno_stats_2bit(const uint8_t *packed, size_t bytes_per_variant, int32_t n_samp,
 	size_t n_variants, int device, int32_t *n_valid, int32_t *allele_sum);
 
-/* Tuning / test hooks: "spa_exact" (every flagged variant through the exact exp/log SPA kernel instead
- * of the cumulant series), "force_dense" (exact g_pos/g_neg pass for every SPA variant), "score_v1"
- * (FP64 gather score kernel instead of the MFMA path), "lanes" (1..4: successive sgx_scan_block /
- * sgx_scan_2bit_dev calls go round-robin over that many streams with their own workspace, so the SPA
- * stage of one block runs under the score stage of the next; call sgx_sync() before reading any
- * output), "pipe_mb" (MiB of input rows per chunk of a host-buffer scan; 0 = default 512), "spa_abl"
- * (diagnostic bits; 512: the SPA kernels scan the rows of a block instead of walking its carrier lists).
- * Results never depend on them beyond rounding (1e-12). */
+/* Tuning / test hooks (per handle; there are no process-wide switches): "spa_exact" (every flagged variant
+ * through the exact exp/log SPA kernel instead of the cumulant series), "force_dense" (exact g_pos/g_neg
+ * pass for every SPA variant), "score_v1" (FP64 gather score kernel instead of the MFMA path), "lanes"
+ * (1..4: successive sgx_scan_block / sgx_scan_2bit_dev calls go round-robin over that many streams with
+ * their own workspace, so the SPA stage of one block runs under the score stage of the next; call
+ * sgx_sync() before reading any output), "pipe_mb" (MiB of input rows per chunk of a host-buffer scan;
+ * 0 = default 512), "spa_abl" (diagnostic bits; 512: the SPA kernels scan the rows of a block instead of
+ * walking its carrier lists).  Results never depend on them beyond rounding (1e-12). */
 int sgx_set_option(sgx_handle *h, const char *name, long long value);
 
 int sgx_sync(sgx_handle *h);
