@@ -4,12 +4,12 @@
     python bench.py --gpus N --steps K --warmup W
     (N>1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path (score stage + SPA stage, through
-sgx_scan_block) over one block of 50 000 variants (the reference's seqParallel
-block size, R/assoc_single.r:204) of synthetic 2-bit genotypes that are already
-resident in this GPU's HBM as genotype blocks (the library's device layout:
-what sgx_block_load leaves there when a block arrives from the GDS file).
-Every step scans a different block.
+A "step" is one pass of the hot path -- rows -> result table: the pass that lists the missing genotypes, the score
+stage and the SPA stage, through sgx_scan_2bit_dev -- over one block of 50 000 variants (the reference's
+seqParallel block size, R/assoc_single.r:204) of synthetic ROW-MAJOR 2-bit genotypes that are already resident in
+this GPU's HBM ("sgx_scan_* on HBM-resident packed genotypes").  Every step scans a different block
+of rows.  Beside the headline: `resident_block` (sgx_scan_block on blocks loaded once -- what a second, third ...
+phenotype over the same genotypes costs per block) and `block_load` (what loading such a block costs).
 
 Workloads; variants shard across ranks, per-GPU work is
 fixed (weak scaling); with 8 GPUs and 25 steps the job is BASELINE config [2]:
@@ -84,9 +84,9 @@ def _physical_cores():
 
 
 class Case:
-    """One configuration resident on this rank's GPU: model, scanner, a pool of loaded genotype blocks."""
+    """One configuration resident on this rank's GPU: model, scanner, a pool of row-major genotype blocks."""
 
-    def __init__(self, workload, k, block, seed, pool_gb, want_blocks, rank, local, n_override=0):
+    def __init__(self, workload, k, block, seed, pool_gb, want_blocks, rank, local, n_override=0, miss_rate=1e-3, n_resident=0):
         import torch
         from saigegds_amd import synth
         from saigegds_amd._lib import Block, Scanner
@@ -95,46 +95,54 @@ class Case:
         self.wl = dict(WORKLOADS[workload])
         if n_override:
             self.wl["n"] = n_override
-        self.workload, self.k, self.block, self.seed, self.rank = workload, k, block, seed, rank
+        self.workload, self.k, self.block, self.seed, self.rank, self.miss_rate = workload, k, block, seed, rank, miss_rate
         self.n = n = self.wl["n"]
         self.dev = torch.device("cuda", local)
         mod = synth.synth_null_model(n, self.wl["trait"], self.wl["prevalence"], n_cov=k, seed=seed)
         self.sm = init_nullmod(mod, np.arange(n), float("nan"), 10.0, 0.1, 0.05, float(mod.var_ratio[0]))
         self.sc = Scanner(self.sm, device=local)
         self.bpv = self.sc.row_stride()
-        self.blk_bytes = Block.nbytes(n, block)
+        self.blk_bytes = block * self.bpv
         self.pool = max(1, min(want_blocks, int(pool_gb * 1e9 // self.blk_bytes)))
-        # one block of row-major rows: the generator's output, rearranged into each block of the pool
-        self.rows = torch.empty((block, self.bpv), dtype=torch.uint8, device=self.dev)
-        self.blocks = [Block(n, block, device=local) for _ in range(self.pool)]
+        # the resident genotypes: row-major 2-bit rows, the generator's output, as a caller of sgx_scan_2bit_dev holds them
+        self.rows = torch.empty((self.pool, block, self.bpv), dtype=torch.uint8, device=self.dev)
         self.out = torch.empty((self.pool, block, 8), dtype=torch.float64, device=self.dev)
         self.valid = torch.empty((self.pool, block), dtype=torch.uint8, device=self.dev)
         t0 = time.time()
-        self.t_load = 0.0
         for b in range(self.pool):
             self.generate_rows(b)
-            t = time.perf_counter()
-            self.sc.load_block_dev(self.blocks[b], self.rows.data_ptr(), self.bpv, block)   # rows -> tiles + lists of the missing genotypes
-            self.sc.sync()
-            self.t_load += time.perf_counter() - t
         self.t_gen = time.time() - t0
+        # a few blocks loaded into the library's resident form (rows + lists of the missing genotypes + carrier lists)
+        self.blocks = [Block(n, block, device=local) for _ in range(min(n_resident, self.pool))]
+        self.res_bytes = Block.nbytes(n, block)
+        self.load_ms = []
+        for b, blk in enumerate(self.blocks):
+            t = time.perf_counter()
+            self.sc.load_block_dev(blk, self.rows[b].data_ptr(), self.bpv, block)
+            self.sc.sync()
+            self.load_ms.append((time.perf_counter() - t) * 1e3)
         limbs, ngroups = self.sc.score_layout()
         self.limbs = [int(x) for x in limbs]
         self.nbf = (sum(self.limbs) + 1 + 15) // 16 + 1 if ngroups else 0      # B fragments of the score kernel (value + bit-1)
 
     def generate_rows(self, b):
-        """the row-major rows of pool block b into self.rows (counter-based generator: any block, any time)"""
+        """the row-major rows of pool block b (counter-based generator: any block, any time)"""
         torch = self.torch
         first = (self.rank * self.pool + b) * self.block
-        thr_d = torch.from_numpy(self.synth.variant_thresholds(first, self.block, self.seed).view(np.int32)).to(self.dev)
+        thr = self.synth.variant_thresholds(first, self.block, self.seed, miss_rate=self.miss_rate)
+        thr_d = torch.from_numpy(thr.view(np.int32)).to(self.dev)
         torch.cuda.synchronize()
-        self.sc.synth_2bit_dev(self.rows.data_ptr(), self.bpv, self.block, first, self.seed, thr_d.data_ptr())
+        self.sc.synth_2bit_dev(self.rows[b].data_ptr(), self.bpv, self.block, first, self.seed, thr_d.data_ptr())
         self.sc.sync()
 
     def step(self, i):
         # asynchronous: the library queues the step on one of its streams (alternating with two lanes);
         # its HIP-event stage times are collected after the timed region
         b = i % self.pool
+        self.sc.scan_2bit_dev(self.rows[b].data_ptr(), self.bpv, self.block, self.out[b].data_ptr(), self.valid[b].data_ptr())
+
+    def step_resident(self, i):
+        b = i % len(self.blocks)
         self.sc.scan_block(self.blocks[b], self.out[b].data_ptr(), self.valid[b].data_ptr())
 
     def close(self):
@@ -161,8 +169,11 @@ class Case:
         }
 
 
-def measure(case, steps, warmup, lanes, world=1, dist=None, rehearse=False):
-    """warmup + K timed steps -> dict(elapsed, stage stats ...); the collective exchange is inside the timed region"""
+def measure(case, steps, warmup, lanes, world=1, dist=None, rehearse=False, resident=False):
+    """warmup + K timed steps -> dict(elapsed, stage stats ...).  resident: the steps scan loaded blocks
+    (sgx_scan_block) instead of row-major rows.  world > 1: the timed region is the product's own sharded scan
+    (saigegds_amd.dist.scan_sharded: the rank's blocks through sgx_scan_2bit_dev on two lanes, then the one
+    exchange of the path, the gather of the result table on rank 0)."""
     torch = case.torch
     sc = case.sc
     lanes = max(1, min(lanes, case.pool))             # L steps in flight need L result buffers
@@ -170,6 +181,7 @@ def measure(case, steps, warmup, lanes, world=1, dist=None, rehearse=False):
     for kv in filter(None, os.environ.get("SGX_BENCH_OPTS", "").split(",")):     # experiments: "name=value,..."
         k, v = kv.split("=")
         sc.set_option(k, int(v))
+    step = case.step_resident if resident else case.step
 
     def barrier():
         torch.cuda.synchronize()
@@ -178,26 +190,28 @@ def measure(case, steps, warmup, lanes, world=1, dist=None, rehearse=False):
         torch.cuda.synchronize()
 
     for i in range(warmup):
-        case.step(i)
+        step(i)
     sc.stats_total(reset=True)      # syncs; drops the warm-up steps from the sums
-    gathered, used = None, None
     if world > 1:
-        # rank 0's receive buffers exist (and are touched) before the clock starts
-        used = sorted({(warmup + i) % case.pool for i in range(steps)})
-        shape = (len(used) * case.block, 8)
-        if case.rank == 0:
-            gathered = [torch.zeros(shape, dtype=torch.float64, device="cpu" if rehearse else case.dev) for _ in range(world)]
+        from saigegds_amd import dist as sdist
+        # this rank's shard: K blocks of rows (the pool's blocks, round-robin), the table of all of them, and on
+        # rank 0 the receive buffers -- everything exists (and is touched) before the clock starts
+        chunks = [case.rows[(warmup + i) % case.pool] for i in range(steps)]
+        m_r = steps * case.block
+        tdev = "cpu" if rehearse else case.dev
+        out_r = torch.zeros((m_r, 8), dtype=torch.float64, device=case.dev)
+        valid_r = torch.zeros((m_r,), dtype=torch.uint8, device=case.dev)
+        recv = sdist.gather_buffers(m_r * world, tdev)
     barrier()
     t0 = time.perf_counter()
-    for i in range(steps):
-        case.step(warmup + i)
-    sc.sync()
-    if world > 1:
-        # the path's one exchange step: result table to rank 0
-        tab = case.out[used].reshape(-1, 8)
-        if rehearse:
-            tab = tab.cpu()
-        dist.gather(tab, gathered, dst=0)
+    if world == 1:
+        for i in range(steps):
+            step(warmup + i)
+        sc.sync()
+    else:
+        sdist.scan_shard(sc, chunks, case.bpv, out_r, valid_r, case.block)
+        so, sv = (out_r.cpu(), valid_r.cpu()) if rehearse else (out_r, valid_r)
+        sdist.gather_table(so, sv, m_r * world, recv=recv)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -211,17 +225,17 @@ def measure(case, steps, warmup, lanes, world=1, dist=None, rehearse=False):
     if lanes > 1:
         sc.set_option("lanes", 1)
         for i in range(2):                 # (the first steps after the switch still see the other lane's tail)
-            case.step(i % case.pool)
+            step(i)
         sc.stats_total(reset=True)
         per = []
         for i in range(9):
-            case.step((2 + i) % case.pool)
+            step(2 + i)
             st = sc.stats()                # (waits for the step: with one lane the next is queued after it anyway)
-            per.append((st["ms_score"], st["ms_spa"], st["ms_kernel"]))
+            per.append((st["ms_score"], st["ms_spa"], st["ms_kernel"], st["ms_lists"]))
         sc.stats_total(reset=True)
         # medians: with the stream idle at submission the events also see the host's gap between two launches,
         # which now and then is hundreds of microseconds
-        iso = tuple(float(np.median([p[k] for p in per])) for k in range(3))
+        iso = tuple(float(np.median([p[k] for p in per])) for k in range(4))
         sc.set_option("lanes", lanes)
     return dict(elapsed=elapsed, tot=tot, iso=iso, lanes=lanes)
 
@@ -239,6 +253,8 @@ def main():
     ap.add_argument("--k", type=int, default=3, help="covariates incl. intercept")
     ap.add_argument("--n-samp", type=int, default=0, help="override N (debug)")
     ap.add_argument("--pool-gb", type=float, default=120.0, help="max HBM for resident genotypes")
+    ap.add_argument("--missing", type=float, default=1e-3, help="missing-genotype rate of the synthetic rows")
+    ap.add_argument("--resident-steps", type=int, default=30, help="steps of the resident-block measurement beside the headline; 0 = skip")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (wall, all cores); 0 = skip")
     ap.add_argument("--seed", type=int, default=20260)
     ap.add_argument("--host-variants", type=int, default=20000,
@@ -287,18 +303,44 @@ def main():
                       "world_size": dist.get_world_size(), "devices": devs}
 
     block, steps, warmup = args.block, args.steps, args.warmup
-    case = Case(args.workload, args.k, block, args.seed, args.pool_gb, steps + warmup, rank, local, args.n_samp)
+    do_res = rank == 0 and world == 1 and args.resident_steps > 0
+    case = Case(args.workload, args.k, block, args.seed, args.pool_gb, steps + warmup, rank, local, args.n_samp,
+                miss_rate=args.missing, n_resident=4 if do_res else 0)
     n, wl, sc, pool = case.n, case.wl, case.sc, case.pool
     r = measure(case, steps, warmup, args.lanes, world, dist, rehearse)
     elapsed, tot, lanes = r["elapsed"], r["tot"], r["lanes"]
+    # ---- beside the headline: blocks loaded once, scanned again (a further phenotype over the same genotypes) ----
+    resident_block, block_load = None, None
+    if do_res and case.blocks:
+        rs = args.resident_steps
+        rr_ = measure(case, rs, 2, args.lanes, resident=True)
+        alg_r = block * (math.ceil(n / 4) + 64)
+        resident_block = {
+            "value": round(rs * block / rr_["elapsed"], 1), "unit": "variants/s", "ms_per_step": round(rr_["elapsed"] / rs * 1e3, 3),
+            "steps": rs, "blocks": len(case.blocks), "entry": "sgx_scan_block on blocks loaded before the clock (sgx_block_load_dev)",
+            "kernel_ms": round(rr_["tot"]["ms_kernel"] / rs, 4), "score_stage_ms": round(rr_["tot"]["ms_score"] / rs, 4),
+            "spa_stage_ms": round(rr_["tot"]["ms_spa"] / rs, 4),
+            "whole_step_frac": round(alg_r * rs / rr_["elapsed"] / 1e9 / HBM_PEAK_GBS, 5),
+            "note": "the lists of the missing genotypes and the carrier lists of the rare variants are the block's, made at load; "
+                    "what every phenotype after the first costs per block of genotypes"}
+        ld = sorted(case.load_ms[1:] or case.load_ms)       # (the first load also pays the first launches)
+        ld_ms = ld[len(ld) // 2]
+        moved = 2 * block * case.bpv
+        block_load = {
+            "ms": round(ld_ms, 3), "entry": "sgx_block_load_dev (rows in HBM -> resident block), host-timed incl. the sync",
+            "bytes_moved": moved, "GBps": round(moved / (ld_ms * 1e-3) / 1e9, 1), "frac_of_hbm_peak": round(moved / (ld_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "block_bytes": case.res_bytes,
+            "note": "one pass reads the rows, writes the block's copy and lists the missing genotypes (bytes_moved = rows read + rows "
+                    "written); a second, partial pass lists the carriers of the rare variants (their rows once more)"}
 
     # ---- per-kernel figures (rank 0's launches) ----------------------------
-    # HIP events recorded by the library on ITS stream around the score stage (score3_kernel with the pass over
-    # the missing genotypes beside it on a side stream, then s3_reduce_kernel and score3_epilogue) and around
-    # the SPA stage (spa4_moments / spa4_solve / spa5_kernel).
+    # HIP events recorded by the library on ITS stream around the list pass (s3_lists_kernel: one read of the rows),
+    # the score stage (the sparse pass over the missing genotypes, score3_kernel, s3_reduce_kernel, score3_epilogue)
+    # and the SPA stage (spa4_moments / spa4_solve / spa5_kernel).
     ms_score = tot["ms_score"] / steps
     ms_spa = tot["ms_spa"] / steps
     ms_kernel = tot["ms_kernel"] / steps     # HIP events around score3_kernel alone, on the stream it is launched on
+    ms_lists = tot["ms_lists"] / steps       # HIP events around the pass that lists the missing genotypes
     n_spa = int(tot["n_spa"])
     n_valid = int(tot["n_valid"])
     nv_tot = steps * block
@@ -311,15 +353,15 @@ def main():
     achieved = alg_bytes / (ms_kernel * 1e-3) / 1e9
     # HBM traffic from the PMC counters: only from a profile of THIS configuration (profiles/README.md)
     traffic, spa_traffic, traffic_src = None, None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r03_pmc_stages.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r04_pmc_stages.json")
     if os.path.exists(pmc_file):
         pm = json.load(open(pmc_file))
         if (pm.get("n_samples") == n and pm.get("variants_per_launch") == block and pm.get("n_covariates") == args.k
                 and pm.get("trait") == wl["trait"] and pm.get("workload") == args.workload):
             traffic = pm.get("score_hbm_bytes_per_launch")
             spa_traffic = pm.get("spa_hbm_bytes_per_step")
-            traffic_src = ("profiles/r03_pmc_stages.json: rocprofv3 --pmc passes of this configuration on another box of "
-                           "the pool (separate passes, gfx950 FETCH_SIZE correction); not measured in this run")
+            traffic_src = ("profiles/r04_pmc_stages.json: rocprofv3 --pmc passes of this configuration and build (separate passes, "
+                           "gfx950 FETCH_SIZE correction; counters cannot be read inside a timed run)")
     spa_alg = n_spa / max(1, steps) * row_bytes      # rows of the flagged variants, read once more
     whole_gbs = alg_bytes * steps / elapsed / 1e9
     binding = max(("hbm", "mfma", "valu_issue"), key=lambda b: bounds[b + "_ms"])
@@ -337,9 +379,13 @@ def main():
         "alone": None if r["iso"] is None else {
             "avg_launch_ms": round(r["iso"][2], 4), "achieved": round(alg_bytes / (r["iso"][2] * 1e-3) / 1e9, 2),
             "frac": round(alg_bytes / (r["iso"][2] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-            "score_stage_ms": round(r["iso"][0], 4), "spa_stage_ms": round(r["iso"][1], 4),
+            "score_stage_ms": round(r["iso"][0], 4), "spa_stage_ms": round(r["iso"][1], 4), "lists_ms": round(r["iso"][3], 4),
             "note": "one lane (no SPA stage of the previous step running beside it), medians of 9 steps outside the timed region"},
         "stages": {
+            "lists": {"avg_ms": round(ms_lists, 4), "kernel": "s3_lists_kernel", "algorithmic_bytes": block * row_bytes,
+                      "frac_of_hbm_peak": round(block * row_bytes / (max(ms_lists, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": "hbm",
+                      "note": "one read of the rows: positions of the missing genotypes for the sparse pass (the rows are read "
+                              "twice per step: here and by score3_kernel)"},
             "score": {"avg_ms": round(ms_score, 4), "launches_per_step": int(tot["score_launches"] // steps),
                       "algorithmic_bytes": alg_bytes, "hbm_bytes": traffic, "bound": BOUND_NAME[binding],
                       "frac_of_hbm_peak": round(alg_bytes / (ms_score * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
@@ -358,12 +404,12 @@ def main():
     # seqParallel block, R/assoc_single.r:204), bounded by --cpu-seconds of wall time.
     cpu = None
     b0 = warmup % pool
-    out, valid, rows, bpv, sm = case.out, case.valid, case.rows, case.bpv, case.sm
+    out, valid, bpv, sm = case.out, case.valid, case.bpv, case.sm
+    rows = case.rows[b0]             # the rows of a timed block (resident: the generator is not run again)
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from concurrent.futures import ThreadPoolExecutor
         from oracle import Oracle
         cores, cpu_model = _physical_cores()
-        case.generate_rows(b0)            # the same rows, regenerated row-major for the oracle
         pilot = rows[:64].cpu().numpy()
         orc0 = Oracle(sm)
         t = time.perf_counter()
@@ -429,7 +475,6 @@ def main():
         from saigegds_amd._lib import PinnedBuffer
         nh = min(block, args.host_variants)
         sc.set_option("lanes", 1)
-        case.generate_rows(b0)
         with PinnedBuffer((nh, bpv)) as pin:
             pin.array[:] = rows[:nh].cpu().numpy()
             sc.scan_2bit(pin.array[:1000])
@@ -442,7 +487,7 @@ def main():
                         np.array_equal(np.nan_to_num(ho, nan=-7.0), np.nan_to_num(out[b0, :nh].cpu().numpy(), nan=-7.0)))
         pcie = 63.0     # GB/s, PCIe Gen5 x16 (MI355X_MICROARCH.md)
         host_path = {"value": round(nh / best, 1), "unit": "variants/s",
-                     "entry": "sgx_scan_2bit (pinned host block in: H2D, rearranged into a block on the device, scanned; table out)",
+                     "entry": "sgx_scan_2bit (pinned host block in: H2D by chunks, each chunk scanned where it lands; table out)",
                      "variants": nh, "GBps_host_to_result": round(nh * (bpv + 65) / best / 1e9, 2), "pcie_peak_GBps": pcie,
                      "frac_of_pcie": round(nh * (bpv + 65) / best / 1e9 / pcie, 4), "same_table_as_resident_scan": same}
 
@@ -454,7 +499,6 @@ def main():
         from saigegds_amd import synth as synth_mod
         from saigegds_amd.gds_write import write_seqarray_genotypes
         nf = min(block, args.file_variants)
-        case.generate_rows(b0)
         host_rows = rows[:nf].cpu().numpy()
         mod = synth_mod.synth_null_model(n, wl["trait"], wl["prevalence"], n_cov=args.k, seed=args.seed)
         with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
@@ -495,25 +539,26 @@ def main():
         "workload": f"{args.workload}: {wl['desc']}, N={n} samples x {block} variants/step/GPU, "
                     f"{wl['trait']} trait" + (f" prevalence {wl['prevalence']}" if wl['trait'] == 'binary' else ""),
         "n_samples": n, "variants_per_step_per_gpu": block, "n_covariates": args.k,
-        "maf_law": "10^U(-3.3,-0.3), 10% alt-major, missing 1e-3", "thresholds": "mac=10 missing=0.1 spa.pval=0.05",
-        "resident_blocks": pool, "sharding": f"variants x{world}", "lanes": lanes,
+        "maf_law": f"10^U(-3.3,-0.3), 10% alt-major, missing {args.missing:g}", "thresholds": "mac=10 missing=0.1 spa.pval=0.05",
+        "resident_row_blocks": pool, "sharding": f"variants x{world}", "lanes": lanes,
         "frac_spa": round(n_spa / max(1, nv_tot), 5), "frac_valid": round(n_valid / max(1, nv_tot), 5),
         "gen_seconds": round(case.t_gen, 2),
-        "resident_format": "genotype blocks (sgx_block: tiles of 16 variants x 256 samples + lists of the missing genotypes), "
-                           "made on the device from the 2-bit rows by sgx_block_load_dev before the timed region",
-        "block_load_ms": round(case.t_load / pool * 1e3, 2), "block_bytes": case.blk_bytes,
-        "score_limbs": case.limbs,
+        "resident_format": "row-major 2-bit rows (4 samples per byte, row stride 128 ceil(N / 512) bytes) in HBM: the input of "
+                           "sgx_scan_2bit_dev; nothing is derived from them before the timed region",
+        "entry": "sgx_scan_2bit_dev" + (" via saigegds_amd.dist.scan_sharded + gather_table" if world > 1 else ""),
+        "row_block_bytes": case.blk_bytes, "score_limbs": case.limbs,
     }
     case.close()
-    del case, out, valid, rows
+    del case, out, valid, rows, r
     torch.cuda.empty_cache()
 
     # ---- other configurations, a few steps each (rank 0, N=1 only) -----------------------------------
     secondary = None
     if rank == 0 and world == 1 and args.secondary and args.workload == "c3" and args.k == 3 and not args.n_samp:
         secondary = {}
-        for name, w2, k2 in (("k13", "c3", 13), ("c2", "c2", 3), ("c4", "c4", 3)):
-            c2 = Case(w2, k2, block, args.seed, min(args.pool_gb, 24.0), 6, rank, local)
+        for name, w2, k2, miss2 in (("k13", "c3", 13, 1e-3), ("c2", "c2", 3, 1e-3), ("c4", "c4", 3, 1e-3),
+                                    ("c3_missing_1e-2", "c3", 3, 1e-2), ("c3_missing_2e-2", "c3", 3, 2e-2)):
+            c2 = Case(w2, k2, block, args.seed, min(args.pool_gb, 24.0), 4, rank, local, miss_rate=miss2)
             r2 = measure(c2, 12, 3, args.lanes)
             alg2, b2 = c2.bounds()
             ms2 = r2["tot"]["ms_score"] / 12
@@ -522,7 +567,8 @@ def main():
             secondary[name] = {
                 "workload": f"{w2}, K={k2}, N={c2.n}", "value": round(12 * block / r2["elapsed"], 1), "unit": "variants/s",
                 "ms_per_step": round(r2["elapsed"] / 12 * 1e3, 3), "steps": 12,
-                "kernel_ms": round(mk2, 4), "score_stage_ms": round(ms2, 4), "spa_stage_ms": round(r2["tot"]["ms_spa"] / 12, 4),
+                "kernel_ms": round(mk2, 4), "lists_ms": round(r2["tot"]["ms_lists"] / 12, 4), "score_stage_ms": round(ms2, 4),
+                "spa_stage_ms": round(r2["tot"]["ms_spa"] / 12, 4), "missing_rate": miss2,
                 "frac": round(alg2 / (mk2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": BOUND_NAME[bind2],
                 "frac_of_binding": round(b2[bind2 + "_ms"] / mk2, 5),
                 "bounds": {k: b2[k] for k in ("hbm_ms", "mfma_ms", "valu_issue_ms", "b_fragments")},
@@ -539,12 +585,13 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": warmup,
             "ms_per_step": round(elapsed / steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-            "dtype_note": "results are formed in FP64 from EXACT integer sums: the per-sample score vectors enter as 40/48/56-bit "
+            "dtype_note": "f64 results from int8-MFMA fixed-point sums: results are formed in FP64 from EXACT integer sums: the per-sample score vectors enter as 40/48/56-bit "
                           "fixed point (int8 limbs on v_mfma_i32_16x16x64_i8, int32 accumulation), a quantisation below the rounding "
                           "of the reference's own double sums (cpu_baseline.gpu_vs_longdouble_max_rel against oracle_vs_longdouble_max_rel)",
             "data": "synthetic",
             "config": config, "rccl_ranks": rccl_ranks,
-            "roofline": roofline, "cpu_baseline": cpu, "host_path": host_path, "from_file": from_file, "secondary": secondary,
+            "roofline": roofline, "resident_block": resident_block, "block_load": block_load,
+            "cpu_baseline": cpu, "host_path": host_path, "from_file": from_file, "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

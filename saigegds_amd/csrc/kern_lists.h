@@ -170,7 +170,8 @@ s3_lists_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, int 
 // per variant: n3 = its listed missing genotypes, ovf = 1 when a range found the pool full; with the carrier
 // counts (resident blocks) also nzv / n2v, the inputs of s3_ingest_clist_count_kernel
 __global__ void __launch_bounds__(256)
-s3_lists_finish_kernel(int M, S3Lists L, int *__restrict__ n3, uint8_t *__restrict__ ovf, int *__restrict__ nzv, int *__restrict__ n2v)
+s3_lists_finish_kernel(int M, S3Lists L, int *__restrict__ n3, uint8_t *__restrict__ ovf, int *__restrict__ nzv, int *__restrict__ n2v,
+	int *__restrict__ info /* may be null: [0] += listed missing genotypes / 64, [1] += variants with a full pool */)
 {
 	const int v = blockIdx.x * 256 + threadIdx.x;
 	if (v < S3_NSUB) L.cursor[(size_t)v * S3_CURSOR_STRIDE] = 0u;   // the pool is handed out: the next load starts at the sub-pools' heads (grid >= S3_NSUB threads)
@@ -186,6 +187,11 @@ s3_lists_finish_kernel(int M, S3Lists L, int *__restrict__ n3, uint8_t *__restri
 	n3[v] = t;
 	ovf[v] = over ? 1 : 0;
 	if (nzv) { nzv[v] = z; n2v[v] = c2; }
+	if (info) {
+		if (t >= 64) atomicAdd(info, t >> 6);
+		else if (t > 0 && (v & 63) == 0) atomicAdd(info, 1);      // (short rows: a coarse count is enough)
+		if (over) atomicAdd(info + 1, 1);
+	}
 }
 
 // Carrier lists of the variants s3_ingest_clist_kernel gave room to (corient 1: the non-zero codes, 2: the codes

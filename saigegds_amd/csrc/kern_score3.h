@@ -69,6 +69,24 @@ __device__ __forceinline__ void s3_unpack_op(uint32_t w, uint32_t &w4, s3_v4i &v
 	else if constexpr (OP == 7) b1[2] = (int)(w4 & 0x02020202u);
 	else if constexpr (OP == 8) b1[3] = (int)(w4 & 0x08080808u);
 }
+// The three-plane form (MISS): beside the value and bit-1 planes the plane [code == 3] x s_t, multiplied into
+// EVERY value column: T3 (the sums over the missing samples) then comes out of the contraction itself and no
+// list of the missing genotypes is needed -- one read of the rows, at any missing rate.  16 operations per dword:
+// the nine above, then  t = w & (w >> 1)  (bit 2 s of t: code s is 3),  m4 = t >> 4,  and four masks -- bytes 1 / 4
+// at the even / odd positions, the position scales again.
+template <int OP>
+__device__ __forceinline__ void s3_unpack3_op(uint32_t w, uint32_t &w4, uint32_t &t, uint32_t &m4, s3_v4i &val, s3_v4i &b1, s3_v4i &mis)
+{
+	if constexpr (OP < 9) s3_unpack_op<OP>(w, w4, val, b1);
+	else if constexpr (OP == 9) t = w >> 1;
+	else if constexpr (OP == 10) t = t & w;
+	else if constexpr (OP == 11) m4 = t >> 4;
+	else if constexpr (OP == 12) mis[0] = (int)(t & 0x01010101u);
+	else if constexpr (OP == 13) mis[1] = (int)(t & 0x04040404u);
+	else if constexpr (OP == 14) mis[2] = (int)(m4 & 0x01010101u);
+	else if constexpr (OP == 15) mis[3] = (int)(m4 & 0x04040404u);
+}
+
 // NBF: B fragments per tile (value fragments + the bit-1 fragment, the LAST one).  NAF: A fragments (16
 // variants) per consumer wave.  NC consumer waves + NLA row-loader waves + NLB B-loader waves per workgroup
 // (one workgroup per CU).
@@ -98,7 +116,10 @@ __device__ __forceinline__ void s3_unpack_op(uint32_t w, uint32_t &w4, s3_v4i &v
 //   through the loaders' registers and ds_write_b128 into a single-tile ring was built first: same memory rate,
 //   but the LDS store path -- ~80 B per clock and CU -- cost 0.18 ms of a 1.07-ms kernel.)
 //   (RM = 2: timing experiment of the tool, wrong results.)
-template <int NBF, int NAF, int NC, int NLA, int NLB, int DA, int DB, int ABL = 0, int NCB = 1, int NBUF_ = 2, int RM = 0>
+// MISS: the three-plane form (s3_unpack3_op): a consumer wave keeps a second set of accumulators, the missing plane
+//   against the NBF - 1 value fragments; its slab is NAF x (2 NBF - 1) fragment slots, the missing plane's behind
+//   the NBF of the two-plane form.  NCB = 1, NBUF = 2 only.
+template <int NBF, int NAF, int NC, int NLA, int NLB, int DA, int DB, int ABL = 0, int NCB = 1, int NBUF_ = 2, int RM = 0, bool MISS = false>
 __global__ void __launch_bounds__(64 * (NC + NLA + NLB), (NC + NLA + NLB + 3) / 4)
 score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3Plan pl, int *__restrict__ out, unsigned long long *__restrict__ stamps)
 {
@@ -447,7 +468,107 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 			par ^= 1;
 		}
 	};
-	if constexpr (NCB == 1) consume(std::integral_constant<int, 0>());
+	// ---- the three-plane consumer (MISS): per dword step the MFMAs run (fragment, plane)-major -- B fragment b feeds the
+	// NAF value MFMAs, then the NAF missing-plane MFMAs, the bit-1 fragment its NAF -- and the 16 NAF operations that
+	// make the NEXT dword's planes (a second set of plane registers) are dealt out evenly behind them.
+	auto consume3 = [&]() {
+		static_assert(!MISS || (NCB == 1 && NBUF_ == 2), "the three-plane form has one column group and two chunk buffers");
+		constexpr int NBV = NBF - 1;                          // value fragments
+		constexpr int NVF = 2 * NBV + 1;                      // (fragment, plane) pairs of a dword step
+		constexpr int NM = NAF * NVF;                         // MFMAs per dword step
+		constexpr int NOPT = 16 * NAF;                        // operations per dword
+		constexpr int BCH = NBF <= 4 ? NBF : 2, NCH = (NBF + BCH - 1) / BCH;
+		const uint32_t bt_lds = smem_lds + (4 * kg * NCOL + r) * 16;
+		s3_v4i acc[NAF][NBF], accm[NAF][NBV > 0 ? NBV : 1];
+#pragma unroll
+		for (int f = 0; f < NAF; f++) {
+#pragma unroll
+			for (int b = 0; b < NBF; b++) acc[f][b] = (s3_v4i){0, 0, 0, 0};
+#pragma unroll
+			for (int b = 0; b < NBV; b++) accm[f][b] = (s3_v4i){0, 0, 0, 0};
+		}
+		int sa = 0, sb = 0, par = 0;
+		while (pc.k < nk) {
+			__builtin_amdgcn_sched_barrier(0);
+			__builtin_amdgcn_s_barrier();
+			__builtin_amdgcn_sched_barrier(0);
+			const uint32_t a_addr = (RM == 1 ? (par ? ring_rm1 : ring_rm0) : ring_lds) + (uint32_t)(sa * SLOT_A);
+			constexpr int AFS = RM == 1 ? 2048 : 1024;
+			const uint32_t b_addr = bt_lds + (uint32_t)(sb * TILE_BYTES);
+			s3_v4i aw[NAF];
+			s3_static_for<0, NAF>([&](auto F) { constexpr int f = decltype(F)::value; S3_DS_READ(aw[f], a_addr, f * AFS); });
+			s3_v4i bf[2][BCH];
+			auto read_chunk = [&](auto CI) {
+				constexpr int ci = decltype(CI)::value, u = ci / NCH, b0 = (ci % NCH) * BCH;
+				s3_static_for<0, BCH>([&](auto J) {
+					constexpr int j = decltype(J)::value;
+					if constexpr (b0 + j < NBF) S3_DS_READ(bf[ci % 2][j], b_addr, u * NCOL * 16 + (b0 + j) * 256);
+				});
+			};
+			constexpr int nread_last = NBF - (NCH - 1) * BCH;
+			auto nreads = [](int c0, int c1) constexpr { int n = 0; for (int c = c0; c < c1 && c < 4 * NCH; c++) n += (c % NCH == NCH - 1) ? nread_last : BCH; return n; };
+			read_chunk(std::integral_constant<int, 0>());
+			S3_LGKM_WAIT(nreads(0, 1), aw[0]);
+#pragma unroll
+			for (int f = 1; f < NAF; f++) S3_TIE(aw[f]);
+			s3_v4i val[2][NAF], b1[2][NAF], mis[2][NAF];
+			uint32_t w4[NAF], tt[NAF], m4[NAF];
+			s3_static_for<0, NOPT>([&](auto O) {
+				constexpr int o = decltype(O)::value, f = o / 16, op = o % 16;
+				s3_unpack3_op<op>((uint32_t)aw[f][0], w4[f], tt[f], m4[f], val[0][f], b1[0][f], mis[0][f]);
+			});
+			__builtin_amdgcn_sched_barrier(0);
+			s3_static_for<0, 4>([&](auto U) {
+				constexpr int u = decltype(U)::value, vb = u & 1, vn = (u + 1) & 1;
+				s3_static_for<0, NM>([&](auto MI) {
+					constexpr int m = decltype(MI)::value, vf = m / NAF, f = m % NAF;
+					constexpr int b = vf < 2 * NBV ? vf / 2 : NBV;            // B fragment
+					constexpr int plane = vf < 2 * NBV ? (vf & 1) : 2;        // 0 value, 1 missing, 2 bit-1
+					constexpr int ch = b / BCH, ci = u * NCH + ch, j = b % BCH;
+					if constexpr (f == 0 && plane != 1 && b % BCH == 0) {
+						// entering a chunk: start the next one, then wait for this one
+						if constexpr (ci + 1 < 4 * NCH) read_chunk(std::integral_constant<int, ci + 1>());
+						constexpr int inflight = nreads(ci + 1, ci + 2);
+						constexpr int nb = (ch == NCH - 1) ? nread_last : BCH;
+						S3_LGKM_WAIT(inflight, bf[ci % 2][0]);
+#pragma unroll
+						for (int jj = 1; jj < nb; jj++) S3_TIE(bf[ci % 2][jj]);
+					}
+					if constexpr (plane == 0) acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(val[vb][f], bf[ci % 2][j], acc[f][b], 0, 0, 0);
+					else if constexpr (plane == 1) accm[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(mis[vb][f], bf[ci % 2][j], accm[f][b], 0, 0, 0);
+					else acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1[vb][f], bf[ci % 2][j], acc[f][b], 0, 0, 0);
+					if constexpr (u < 3) {
+						s3_static_for<m * NOPT / NM, (m + 1) * NOPT / NM>([&](auto O) {
+							constexpr int o = decltype(O)::value, ff = o / 16, op = o % 16;
+							s3_unpack3_op<op>((uint32_t)aw[ff][u + 1], w4[ff], tt[ff], m4[ff], val[vn][ff], b1[vn][ff], mis[vn][ff]);
+						});
+					}
+					__builtin_amdgcn_sched_barrier(0);
+				});
+			});
+			if (pc.t + 1 == pc.t1) {
+				// the item's slab: [wave][f][slot < 2 NBF - 1][reg][lane], the missing plane's fragments behind the NBF
+				int *dst = out + ((size_t)pc.id * NC + wid) * (NAF * NVF * 256) + lane;
+#pragma unroll
+				for (int f = 0; f < NAF; f++) {
+#pragma unroll
+					for (int b = 0; b < NBF; b++)
+#pragma unroll
+						for (int reg = 0; reg < 4; reg++) { dst[((f * NVF + b) * 4 + reg) * 64] = acc[f][b][reg]; acc[f][b][reg] = 0; }
+#pragma unroll
+					for (int b = 0; b < NBV; b++)
+#pragma unroll
+						for (int reg = 0; reg < 4; reg++) { dst[((f * NVF + NBF + b) * 4 + reg) * 64] = accm[f][b][reg]; accm[f][b][reg] = 0; }
+				}
+			}
+			pos_next(pc);
+			if (RM != 1 || par) sa = sa + 1 == RA ? 0 : sa + 1;
+			sb = sb + 1 == RB ? 0 : sb + 1;
+			par ^= 1;
+		}
+	};
+	if constexpr (MISS) consume3();
+	else if constexpr (NCB == 1) consume(std::integral_constant<int, 0>());
 	else s3_static_for<0, NCB>([&](auto CG) { if (cgr == decltype(CG)::value) consume(CG); });
 	if ((ABL & 16) && tid == 0) {
 		stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0;
@@ -464,6 +585,11 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 	X(2, 4, 8, 3, 1, 1, 2) X(3, 4, 8, 3, 1, 1, 1) X(4, 4, 8, 3, 1, 1, 1) X(5, 3, 8, 3, 1, 1, 2) X(6, 3, 8, 3, 1, 1, 1) \
 	X(7, 4, 4, 2, 2, 2, 1) X(8, 4, 4, 2, 2, 2, 1) X(9, 4, 4, 2, 2, 1, 1) X(10, 4, 4, 2, 2, 1, 1) X(11, 4, 4, 2, 2, 1, 1) \
 	X(12, 3, 4, 2, 2, 1, 1) X(13, 3, 4, 2, 2, 1, 1) X(14, 2, 4, 2, 2, 2, 1) X(15, 2, 4, 2, 2, 1, 1) X(16, 2, 4, 2, 2, 1, 1)
+// ... and of the three-plane form (MISS: no lists of the missing genotypes; 4 NAF (2 NBF - 1) accumulators per wave)
+#define S3_FOR_EACH_NBF_MISS(X) \
+	X(2, 4, 8, 3, 1, 1, 2) X(3, 3, 8, 3, 1, 1, 2) X(4, 2, 8, 3, 1, 2, 2) X(5, 2, 8, 3, 1, 2, 2) X(6, 3, 4, 2, 2, 2, 1) \
+	X(7, 2, 4, 2, 2, 2, 1) X(8, 2, 4, 2, 2, 2, 1) X(9, 2, 4, 2, 2, 2, 1) X(10, 2, 4, 2, 2, 2, 1) X(11, 1, 4, 2, 2, 2, 1) \
+	X(12, 1, 4, 2, 2, 2, 1) X(13, 1, 4, 2, 2, 2, 1) X(14, 1, 4, 2, 2, 2, 1) X(15, 1, 4, 2, 2, 2, 1) X(16, 1, 4, 2, 2, 2, 1)
 static inline size_t s3_lds_bytes(int NBF, int NAF, int NC, int DA, int DB) { return ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * 2 * NC * NAF) * 1024; }
 
 #ifndef S3_KERNEL_ONLY   /* tools/score3_bench.hip takes the contraction kernel alone */
@@ -628,18 +754,27 @@ s3_reduce_kernel(S3Plan pl, int M, int NCW, int NAF, int NBF, int NCB, const int
 // missing genotypes are not listed go onto `ovf_list` (counters[23]) for the FP64 kernel.
 template <int K>
 __global__ void __launch_bounds__(256)
-score3_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf, const long long *__restrict__ t3part /* [M][P][2] totals */,
+score3_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf, int acc_stride, int miss_off,
+	const long long *__restrict__ t3part /* [M][P][2] totals */,
 	const int *__restrict__ n3buf, const uint8_t *__restrict__ ovf, int *__restrict__ ovf_list,
 	SpaRec *__restrict__ recs, int *__restrict__ counters, int btop, int *__restrict__ fb_series, int *__restrict__ fb_exact,
 	double *__restrict__ out8, uint8_t *__restrict__ valid)
 {
 	constexpr int P = 2 * K + 2, CW = P - 1;     // score columns c' (K), e (K), s, w; column CW carries G^2
 	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	// miss_off = 0: the sums over the missing samples come from the sparse pass (t3part, n3buf; variants it could not
+	// list go to the FP64 kernel); miss_off > 0: the three-plane form, the missing plane's limb sums sit at that
+	// offset of the variant's row (and its constant column counts the missing genotypes)
+	const int *a0 = accbuf + (size_t)min(j, M - 1) * acc_stride;
+	const int n3 = j < M ? (miss_off ? a0[miss_off + ep.col_ones] / 4 : n3buf[j]) : 0;
+	{
+		// census of the step's missing genotypes (units of 64) for the host's choice between the two forms
+		const int tot = wave_total_i(n3);
+		if ((threadIdx.x & 63) == 0 && tot >= 64) atomicAdd(&counters[22], tot >> 6);
+	}
 	if (j >= M) return;
-	if (ovf[j]) { ovf_list[atomicAdd(&counters[23], 1)] = j; return; }
-	const int *a0 = accbuf + (size_t)j * ep.acc_stride;
+	if (!miss_off && ovf[j]) { ovf_list[atomicAdd(&counters[23], 1)] = j; return; }
 	const int N = md.N;
-	const int n3 = n3buf[j];
 	const long long AC = (long long)(a0[ep.col_ones] / 4) - 3ll * n3;
 	const int n2 = a0[ep.col_b1 + ep.climb[CW]] / 8 - n3;  // bit-1 plane (0/2) against the constant column (4)
 	const int n1 = (int)(AC - 2ll * n2);
@@ -647,7 +782,11 @@ score3_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf, co
 	double *o = out8 + (size_t)j * 8;
 	if (!h.pass) { nan_row(o); valid[j] = 0; return; }
 	const double imp = 2 * h.AF;
-	auto t3_of = [&](int c) -> HiLo { const long long *p = t3part + ((size_t)j * P + c) * 2; return hl(p[0], p[1]); };
+	auto t3_of = [&](int c) -> HiLo {
+		if (miss_off) return mf_limbs(a0 + miss_off + ep.ccol[c], ep.climb[c]);
+		const long long *p = t3part + ((size_t)j * P + c) * 2;
+		return hl(p[0], p[1]);
+	};
 	double acc[P];
 	HiLo Wm = hl(0, 0), T3m = hl(0, 0);
 #pragma unroll

@@ -105,6 +105,9 @@ struct sgx_block {
 	hipEvent_t ready = nullptr;  // recorded behind the last load: scans on other streams wait for it
 	hipEvent_t last_read = nullptr;   // recorded behind the last scan that reads the block: a reload waits for it
 	bool was_read = false;
+	// census of the last load (s3_lists_finish_kernel): [0] listed missing genotypes / 64, [1] variants the pool had no room for
+	int *info = nullptr, *h_info = nullptr;
+	bool info_read = false, dense = false;
 };
 
 struct sgx_handle {
@@ -140,6 +143,7 @@ struct sgx_handle {
 	long long *s3_t3 = nullptr; size_t s3_t3_cap = 0;
 	int *s3_ovf = nullptr; size_t s3_ovf_cap = 0;
 	bool s3_attr[17] = {false};       // per NBF: dynamic LDS size raised
+	bool s3_attr_miss[17] = {false};  // ... of the three-plane form
 	hipStream_t s3_side = nullptr;    // the sparse pass over the missing genotypes runs beside the contraction kernel
 	hipEvent_t s3_fork = nullptr, s3_join = nullptr;
 	sgx_block *tmp_blk[2] = {nullptr, nullptr};   // row-major calls: the rows are ingested into a block first
@@ -165,6 +169,8 @@ struct sgx_handle {
 	hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 	hipEvent_t evk[2] = {nullptr, nullptr};    // around the contraction kernel alone (stats.ms_kernel)
 	bool evk_set = false;
+	hipEvent_t ev_lists = nullptr;             // in front of the list pass of a row-major call (stats.ms_lists = ev_lists .. ev[0])
+	bool lists_timed = false;
 	sgx_stats stats{};
 	bool force_v1 = false;            // "score_v1" option: gather kernel instead of the MFMA path
 	bool stats_pending = false;
@@ -180,11 +186,20 @@ struct sgx_handle {
 	int n_lanes = 1;
 	sgx_handle *owner = nullptr;      // set in a twin
 	bool shares_model = false;        // twin: dF .. dFl belong to the owner
+	// primary: the three-plane form of the contraction kernel (no lists of the missing genotypes, cost independent of
+	// the missing rate) for calls that would build lists -- set when a finished step listed more than SGX_DENSE_ON of
+	// its genotypes as missing (or overflowed the pool), cleared when a three-plane step counted fewer than SGX_DENSE_OFF
+	bool dense_mode = false;
+	int dense_opt = -1;               // "three_plane" option: -1 automatic, 0 never, 1 always
+	bool used_miss = false;           // this lane's call in flight took the three-plane form
 	int next_lane = 0;                // primary: which lane takes the next _dev call
 	sgx_handle *last_issued = nullptr;// primary: lane of the most recent call
 	sgx_stats total{};                // primary: sums over harvested calls (sgx_get_stats_total)
 	uint64_t total_calls = 0;
 };
+
+#define SGX_DENSE_ON  0.005       /* see rows_take_three_planes */
+#define SGX_DENSE_OFF 0.003
 
 static int set_dev(sgx_handle *h)
 {
@@ -310,6 +325,7 @@ static int alloc_workspace(sgx_handle *h)
 	HIPCHK(hipHostMalloc((void **)&h->h_counters, 24 * sizeof(int), hipHostMallocDefault));
 	for (int i = 0; i < 3; i++) HIPCHK(hipEventCreate(&h->ev[i]));
 	for (int i = 0; i < 2; i++) HIPCHK(hipEventCreate(&h->evk[i]));
+	HIPCHK(hipEventCreate(&h->ev_lists));
 	// SPA scratch: one (adj, mu) list of N entries per resident workgroup
 	hipDeviceProp_t prop;
 	HIPCHK(hipGetDeviceProperties(&prop, h->device));
@@ -588,6 +604,7 @@ extern "C" void sgx_free(sgx_handle *h)
 	if (h->h_counters) (void)hipHostFree(h->h_counters);
 	for (int i = 0; i < 3; i++) if (h->ev[i]) (void)hipEventDestroy(h->ev[i]);
 	for (int i = 0; i < 2; i++) if (h->evk[i]) (void)hipEventDestroy(h->evk[i]);
+	if (h->ev_lists) (void)hipEventDestroy(h->ev_lists);
 	if (h->s3_side) { (void)hipStreamSynchronize(h->s3_side); (void)hipStreamDestroy(h->s3_side); }
 	if (h->s3_fork) (void)hipEventDestroy(h->s3_fork);
 	if (h->s3_join) (void)hipEventDestroy(h->s3_join);
@@ -623,7 +640,7 @@ static int ensure_recs(sgx_handle *h, size_t n)
 	if (h->mf_ok) {
 		if (h->mf_acc) HIPCHK(hipFree(h->mf_acc));
 		h->mf_acc = nullptr;
-		HIPCHK(hipMalloc((void **)&h->mf_acc, n * (size_t)h->mfe.acc_stride * sizeof(int)));
+		HIPCHK(hipMalloc((void **)&h->mf_acc, n * (size_t)(2 * h->mfe.acc_stride - 16) * sizeof(int)));   // (three-plane form: 2 NBF - 1 fragment slots)
 	}
 	h->recs_cap = n;
 	return SGX_OK;
@@ -852,6 +869,7 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 	else if (n == "spa_exact") h->force_exact = value != 0;
 	else if (n == "pipe_mb") { if (value < 0 || value > 65536) return fail(SGX_EINVAL, "pipe_mb out of range"); h->pipe_bytes = (size_t)value << 20; return SGX_OK; }
 	else if (n == "spa_abl") h->spa_abl = (int)value;
+	else if (n == "three_plane") { if (value < -1 || value > 1) return fail(SGX_EINVAL, "three_plane must be -1 (automatic), 0 or 1"); h->dense_opt = (int)value; return SGX_OK; }
 	else if (n == "lanes") {
 		if (value < 1 || value > 4) return fail(SGX_EINVAL, "lanes must be 1..4");
 		if (h->owner) return fail(SGX_EINVAL, "lanes: not on a twin");
@@ -899,6 +917,16 @@ static int sync_lane(sgx_handle *h)
 		h->stats.n_valid = (uint64_t)h->h_counters[1];
 		h->stats.n_spa_dense = (uint64_t)h->h_counters[2];
 		h->stats.n_spa_slow = (uint64_t)h->h_counters[4];
+		h->stats.three_plane = h->used_miss ? 1u : 0u;
+		h->stats.n_unlisted = (uint32_t)h->h_counters[23];
+		{
+			// the step's missing genotypes (census of the epilogue, units of 64) decide the form of the NEXT row-major calls
+			sgx_handle *p = h->owner ? h->owner : h;
+			const double frac = 64.0 * (double)h->h_counters[22] / ((double)std::max<uint64_t>(1, h->stats.n_variants) * (double)h->md.N);
+			const bool over = (uint64_t)h->h_counters[23] * 32 > h->stats.n_variants;
+			if (!h->used_miss && (frac > SGX_DENSE_ON || over)) p->dense_mode = true;
+			else if (h->used_miss && frac < SGX_DENSE_OFF) p->dense_mode = false;
+		}
 #ifdef SPA5_PROF
 		fprintf(stderr, "routing: tier A %d, tier B %d (of them handed on by A: %d), per-variant kernels %d (series list %d, exact list %d), dense %d\n",
 			h->h_counters[0], h->h_counters[7], h->h_counters[6], h->h_counters[5], h->h_counters[3], h->h_counters[4], h->h_counters[2]);
@@ -914,13 +942,18 @@ static int sync_lane(sgx_handle *h)
 		float k = 0;
 		if (h->evk_set) (void)hipEventElapsedTime(&k, h->evk[0], h->evk[1]);
 		h->stats.ms_kernel = k; h->evk_set = false;
+		float l = 0;
+		if (h->lists_timed) { (void)hipEventElapsedTime(&l, h->ev_lists, h->ev[0]); h->stats.ms_total += l; }
+		h->stats.ms_lists = l; h->lists_timed = false;
 		h->stats_pending = false;
 		sgx_handle *p = h->owner ? h->owner : h;
 		const sgx_stats &x = h->stats;
 		p->total.n_variants += x.n_variants; p->total.n_valid += x.n_valid; p->total.n_spa += x.n_spa;
 		p->total.n_spa_dense += x.n_spa_dense; p->total.n_spa_slow += x.n_spa_slow;
 		p->total.ms_score += x.ms_score; p->total.ms_spa += x.ms_spa; p->total.ms_total += x.ms_total; p->total.ms_kernel += x.ms_kernel;
+		p->total.ms_lists += x.ms_lists;
 		p->total.score_launches += x.score_launches; p->total.spa_launches += x.spa_launches;
+		p->total.three_plane += x.three_plane; p->total.n_unlisted += x.n_unlisted;
 		p->total_calls++;
 	}
 	return SGX_OK;
@@ -988,6 +1021,8 @@ extern "C" void sgx_block_free(sgx_block *b)
 	(void)hipFree(b->rows); (void)hipFree(b->idx); (void)hipFree(b->cursor); (void)hipFree(b->lstart); (void)hipFree(b->lcnt);
 	(void)hipFree(b->nzp); (void)hipFree(b->n2p); (void)hipFree(b->n3); (void)hipFree(b->ovf);
 	(void)hipFree(b->nzv); (void)hipFree(b->n2v); (void)hipFree(b->cptr); (void)hipFree(b->cidx); (void)hipFree(b->corient);
+	(void)hipFree(b->info);
+	if (b->h_info) (void)hipHostFree(b->h_info);
 	if (b->ready) (void)hipEventDestroy(b->ready);
 	if (b->last_read) (void)hipEventDestroy(b->last_read);
 	delete b;
@@ -1018,6 +1053,9 @@ static int block_create(int32_t n_samp, size_t max_variants, int device, bool li
 	if (e == hipSuccess) e = hipMalloc((void **)&b->lcnt, nrc * sizeof(int));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->n3, max_variants * sizeof(int));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->ovf, max_variants);
+	if (e == hipSuccess) e = hipMalloc((void **)&b->info, 2 * sizeof(int));
+	if (e == hipSuccess) e = hipMemset(b->info, 0, 2 * sizeof(int));
+	if (e == hipSuccess) e = hipHostMalloc((void **)&b->h_info, 2 * sizeof(int), hipHostMallocDefault);
 	if (!lists_only) {
 		if (e == hipSuccess) e = hipMalloc((void **)&b->nzp, nrc * sizeof(int));
 		if (e == hipSuccess) e = hipMalloc((void **)&b->n2p, nrc * sizeof(int));
@@ -1083,7 +1121,7 @@ static int block_finish(sgx_block *b, size_t M, hipStream_t st)
 {
 	const S3Lists L = block_lists(b);
 	hipLaunchKernelGGL(s3_lists_finish_kernel, dim3((unsigned)((std::max<size_t>(M, S3_NSUB) + 255) / 256)), dim3(256), 0, st, (int)M, L, b->n3, b->ovf,
-		b->lists_only ? (int *)nullptr : b->nzv, b->lists_only ? (int *)nullptr : b->n2v);
+		b->lists_only ? (int *)nullptr : b->nzv, b->lists_only ? (int *)nullptr : b->n2v, b->lists_only ? (int *)nullptr : b->info);
 	if (!b->lists_only) {
 		hipLaunchKernelGGL(s3_ingest_clist_count_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, b->N, SPA5_NNZ, b->nzv, b->n2v, b->n3, b->corient);
 		hipLaunchKernelGGL(s3_ingest_clist_kernel, dim3(1), dim3(1024), 0, st, (int)M, (unsigned)b->cidx_cap, b->nzv, b->cptr, b->corient);
@@ -1091,6 +1129,11 @@ static int block_finish(sgx_block *b, size_t M, hipStream_t st)
 			b->corient, b->cptr, b->cidx);
 	}
 	HIPCHK(hipGetLastError());
+	if (!b->lists_only) {
+		HIPCHK(hipMemcpyAsync(b->h_info, b->info, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+		HIPCHK(hipMemsetAsync(b->info, 0, 2 * sizeof(int), st));
+		b->info_read = false;
+	}
 	HIPCHK(hipEventRecord(b->ready, st));
 	b->M = M;
 	return SGX_OK;
@@ -1152,7 +1195,9 @@ static int ensure_buf(sgx_handle *h, T **p, size_t *cap, size_t need)
 // Scan of a block (resident, or the lists of a row-major call with the caller's rows) on this lane's stream: sparse
 // pass over the missing genotypes, contraction, reduction, epilogue, the FP64 kernel for what the lists do not
 // cover, SPA stage.
-static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double *out8, uint8_t *valid, bool lazy_dense = false)
+// miss: the three-plane form -- the sums over the missing samples come out of the contraction kernel, the block's lists
+// are not read (and need not exist)
+static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double *out8, uint8_t *valid, bool lazy_dense = false, bool miss = false)
 {
 	const DevModel &md = h->md;
 	const MfEpi &ep = h->mfe;
@@ -1163,12 +1208,40 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	const S3Lists L = block_lists(b);
 	S3Plan pl{};
 	int NCW = 0, NAFW = 0;
+	const int slots = miss ? 2 * NBF - 1 : NBF;      // fragment slots of a variant's row of limb sums
+	h->used_miss = miss;
 	HIPCHK(hipStreamWaitEvent(st, b->ready, 0));
 	HIPCHK(hipEventRecord(h->ev[0], st));            // (counters and queue cursors: zeroed by s3_reduce_kernel)
 	int rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)(b->nr + 1) * M * md.P * 2);      // per-range partials, then the totals
 	if (rc) return rc;
 	rc = ensure_buf(h, &h->s3_ovf, &h->s3_ovf_cap, M);
 	if (rc) return rc;
+	if (miss) {
+		switch (NBF) {
+#define S3CASE(NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_)                                                         \
+		case NBF_: {                                                                                          \
+			NCW = NC_; NAFW = NAF_;                                                                           \
+			pl = s3_plan(M, b->ntile, grid, NAF_ * NC_, rr.bpv);                                              \
+			rc = ensure_buf(h, &h->s3_slabs, &h->s3_slabs_cap, (size_t)pl.ng * pl.ipg * NC_ * NAF_ * (2 * NBF_ - 1) * 256); \
+			if (rc) return rc;                                                                                \
+			const size_t lds = s3_lds_bytes(NBF_, NAF_, NC_, DA_, DB_);                                       \
+			auto kern = score3_kernel<NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_, 0, 1, 2, 1, true>;                \
+			if (!h->s3_attr_miss[NBF_]) {                                                                     \
+				HIPCHK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+				h->s3_attr_miss[NBF_] = true;                                                                 \
+			}                                                                                                 \
+			HIPCHK(hipEventRecord(h->evk[0], st));                                                            \
+			hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * (NC_ + NLA_ + NLB_)), lds, st,            \
+				rr.base, (const uint8_t *)h->dFl, pl, h->s3_slabs, (unsigned long long *)nullptr);            \
+			HIPCHK(hipEventRecord(h->evk[1], st));                                                            \
+			h->evk_set = true;                                                                                \
+		} break;
+			S3_FOR_EACH_NBF_MISS(S3CASE)
+#undef S3CASE
+		default: return fail(SGX_EINVAL, "score3: %d B fragments not supported", NBF);
+		}
+		HIPCHK(hipGetLastError());
+	} else {
 	// Sums over the missing samples, on the side stream, FIRST; the contraction kernel waits for them:
 	//  * with few fragments (3 waves of ~154 registers per SIMD) the pass finds no room beside a resident
 	//    contraction workgroup; launched second it would wait for the kernel's end;
@@ -1219,17 +1292,19 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	default: return fail(SGX_EINVAL, "score3: %d B fragments not supported", NBF);
 	}
 	HIPCHK(hipGetLastError());
+	}
+	const int acc_stride = 16 * slots;
 	{
-		const int per = NCW * NAFW * NBF * 256;
+		const int per = NCW * NAFW * slots * 256;
 		hipLaunchKernelGGL(s3_reduce_kernel, dim3((unsigned)((per / 4 + 255) / 256), (unsigned)pl.vt), dim3(256), 0, st,
-			pl, (int)M, NCW, NAFW, NBF, 1, h->s3_slabs, h->mf_acc, ep.acc_stride, h->counters, h->cur5);
+			pl, (int)M, NCW, NAFW, slots, 1, h->s3_slabs, h->mf_acc, acc_stride, h->counters, h->cur5);
 	}
 	const int btop = md.quant ? 0 : (int)(2 * M);
 	switch (md.K) {
 #define ECASE(KK) case KK:                                                                     \
-	hipLaunchKernelGGL((score3_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, md, ep, h->mf_acc, \
-		h->s3_t3 + (size_t)b->nr * M * md.P * 2, b->n3, b->ovf, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid); \
-	hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, 256>), dim3((unsigned)std::min<size_t>(M, 4 * (size_t)h->n_cu)), dim3(256), 0, st, \
+	hipLaunchKernelGGL((score3_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, md, ep, h->mf_acc, acc_stride, \
+		miss ? 16 * NBF : 0, h->s3_t3 + (size_t)b->nr * M * md.P * 2, b->n3, b->ovf, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid); \
+	if (!miss) hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, 256>), dim3((unsigned)std::min<size_t>(M, 4 * (size_t)h->n_cu)), dim3(256), 0, st, \
 		rr, (int)M, md, h->recs, h->counters, out8, valid, (const int *)h->s3_ovf, 23, btop, h->fb_spa2, h->fb_x2); \
 	break;
 	FOR_EACH_K(ECASE)
@@ -1312,7 +1387,29 @@ extern "C" int sgx_scan_block(sgx_handle *h, const sgx_block *b, double *out8_de
 		lane->stats_pending = true;
 		return SGX_OK;
 	}
-	return launch_block_scan(lane, b, b->M, out8_dev, valid_dev, true);
+	// a block with many missing genotypes (or variants its pool had no room for) takes the three-plane form
+	sgx_block *bw = const_cast<sgx_block *>(b);
+	if (!bw->info_read) {
+		HIPCHK(hipEventSynchronize(b->ready));
+		const double frac = 64.0 * (double)b->h_info[0] / ((double)b->M * (double)b->N);
+		bw->dense = frac > SGX_DENSE_ON || (size_t)b->h_info[1] * 32 > b->M;
+		bw->info_read = true;
+	}
+	const bool miss = h->dense_opt >= 0 ? h->dense_opt != 0 : b->dense;
+	return launch_block_scan(lane, b, b->M, out8_dev, valid_dev, true, miss);
+}
+
+// Which form of the contraction kernel a call takes.  The two-plane form needs the positions of the missing genotypes
+// (a pass over the rows, or a resident block's lists) and a sparse pass whose cost grows with their number; the
+// three-plane form needs neither, at ~1.7 x the MFMAs.  Measured (tools/README.md, round 4): up to 3 B fragments
+// (quantitative traits, K <= 2) the three-plane kernel costs what the two-plane kernel does and saves the list pass;
+// from 4 fragments on it pays once more than ~0.5 % of the genotypes are missing -- where the sparse pass has grown
+// to the difference and the pool of the lists (0.8 %) is about to overflow.
+static bool rows_take_three_planes(const sgx_handle *lane)
+{
+	const sgx_handle *p = lane->owner ? lane->owner : lane;
+	if (p->dense_opt >= 0) return p->dense_opt != 0;
+	return lane->mf_nbfv[0] + 1 <= 3 || p->dense_mode;
 }
 
 // the lists of this lane's row-major calls (the rows stay where the caller has them)
@@ -1333,6 +1430,9 @@ static int scan_rows_dev(sgx_handle *lane, int which, const uint8_t *rows_dev, s
 	if (rc) return rc;
 	sgx_block *tb = lane->tmp_blk[which];
 	tb->ext_rows = rows_dev; tb->ext_bpv = bpv;
+	if (rows_take_three_planes(lane)) return launch_block_scan(lane, tb, M, out8, valid, lazy_dense, true);
+	HIPCHK(hipEventRecord(lane->ev_lists, lane->stream));
+	lane->lists_timed = true;
 	rc = block_put_rows(tb, rows_dev, bpv, 0, M, lane->stream);
 	if (!rc) rc = block_finish(tb, M, lane->stream);
 	if (rc) return rc;
@@ -1469,7 +1569,9 @@ static int scan_host(sgx_handle *h, const void *rows, size_t src_row_bytes, size
 		total.n_variants += x.n_variants; total.n_valid += x.n_valid; total.n_spa += x.n_spa;
 		total.n_spa_dense += x.n_spa_dense; total.n_spa_slow += x.n_spa_slow;
 		total.ms_score += x.ms_score; total.ms_spa += x.ms_spa; total.ms_total += x.ms_total;
+		total.ms_kernel += x.ms_kernel; total.ms_lists += x.ms_lists;
 		total.score_launches += x.score_launches; total.spa_launches += x.spa_launches;
+		total.three_plane = std::max(total.three_plane, x.three_plane); total.n_unlisted += x.n_unlisted;      // (any chunk)
 		return SGX_OK;
 	};
 	size_t prev_off = 0, prev_m = 0;

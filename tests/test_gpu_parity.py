@@ -405,6 +405,70 @@ def test_block_reload_without_sync_waits_for_its_readers():
     assert_table_close(got, gv, ref, ref_valid, what="reload without sync")
 
 
+@pytest.mark.parametrize("trait,k,miss", [("binary", 3, 1e-3), ("binary", 3, 0.04), ("quantitative", 3, 0.02), ("binary", 6, 0.02),
+                                          ("binary", 13, 0.01), ("quantitative", 13, 0.0)])
+def test_three_plane_form_equals_two_plane_form(trait, k, miss):
+    """The contraction kernel has two forms: two planes + the sparse pass over the listed missing genotypes, and
+    three planes (the sums over the missing samples from a third MFMA plane: no lists).  Both are exact integer
+    arithmetic on the same fixed-point values, so the score stage's integers are the same and the tables agree to
+    the last bit wherever the SPA stage is not involved, to rounding where it is; both against the oracle."""
+    sm, packed = _synthetic_case(3001, 900, trait, 0.05, seed=53, k=k, miss=miss)
+    ref, ref_valid = _oracle(sm).scan_2bit(packed)
+    res = {}
+    with _scanner(sm) as sc:
+        for form in (0, 1):
+            sc.set_option("three_plane", form)
+            out, valid = sc.scan_2bit(packed)
+            st = sc.stats()
+            assert st["three_plane"] == form, st
+            assert_table_close(out, valid, ref, ref_valid, quant=sm.quant, what=f"three_plane={form} {trait} K={k} miss={miss}")
+            res[form] = (out, valid)
+    assert np.array_equal(res[0][1], res[1][1])
+    v = ref_valid.astype(bool)
+    assert np.array_equal(res[0][0][v][:, :3], res[1][0][v][:, :3])
+    cols = slice(3, 6) if sm.quant else slice(3, 7)
+    np.testing.assert_allclose(res[0][0][v][:, cols], res[1][0][v][:, cols], rtol=1e-11)
+
+
+def test_missing_rate_picks_the_form():
+    """Automatic choice: a binary model with K = 3 starts on the two-plane form (lists of the missing genotypes);
+    a step that finds more than 0.5 % of its genotypes missing turns the following row-major calls to the
+    three-plane form, a three-plane step with few missing genotypes turns them back; resident blocks decide from
+    the census of their own load.  Tables are the oracle's either way."""
+    import torch
+    from saigegds_amd._lib import Block
+    dev = torch.device("cuda", 0)
+    sm, dirty = _synthetic_case(3001, 800, "binary", 0.05, seed=59, miss=0.03)
+    _, clean = _synthetic_case(3001, 800, "binary", 0.05, seed=59, miss=1e-3)
+    orc = _oracle(sm)
+    with _scanner(sm) as sc, Block(sm.n, 800) as b_dirty, Block(sm.n, 800) as b_clean:
+        bpv = sc.row_stride()
+
+        def dev_rows(p):
+            t = torch.zeros((800, bpv), dtype=torch.uint8, device=dev)
+            t[:, :p.shape[1]] = torch.from_numpy(p).to(dev)
+            return t
+
+        rows = {"dirty": dev_rows(dirty), "clean": dev_rows(clean)}
+        out = torch.zeros((800, 8), dtype=torch.float64, device=dev)
+        valid = torch.zeros(800, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        seq = [("dirty", 0), ("dirty", 1), ("clean", 1), ("clean", 0), ("clean", 0)]
+        for name, want in seq:
+            sc.scan_2bit_dev(rows[name].data_ptr(), bpv, 800, out.data_ptr(), valid.data_ptr())
+            st = sc.stats()
+            assert st["three_plane"] == want, (name, want, st)
+            ref, ref_valid = orc.scan_2bit(dirty if name == "dirty" else clean)
+            assert_table_close(out.cpu().numpy(), valid.cpu().numpy(), ref, ref_valid, what=f"{name} rows, three_plane={want}")
+        sc.load_block(b_dirty, dirty)
+        sc.load_block(b_clean, clean)
+        for blk, p, want in ((b_dirty, dirty, 1), (b_clean, clean, 0)):
+            o, v = _scan_block(sc, blk, 800)
+            assert sc.stats()["three_plane"] == want
+            ref, ref_valid = orc.scan_2bit(p)
+            assert_table_close(o, v, ref, ref_valid, what=f"block, three_plane={want}")
+
+
 def test_two_lanes_give_identical_tables():
     """"lanes" = 2 .. 4: successive device-resident scans go round-robin over that many streams with their own
     workspace; every block's table must equal the single-lane one, and the totals must add up."""

@@ -37,19 +37,19 @@ __global__ void fill_codes(uint32_t *dst, size_t ndw, uint64_t seed)
 
 struct Shape { int N; size_t M; };
 
-template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int ABL, int NCB = 1, int NBUF = 2, int RM = 0>
+template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int ABL, int NCB = 1, int NBUF = 2, int RM = 0, bool MISS = false>
 static float run(const char *name, const uint8_t *A, const uint8_t *Fl, int ntile, size_t M, int wg_per_cu, int n_cu, int *out, size_t out_ints,
 	int reps, S3Plan *plan_out = nullptr, size_t bpv = 0)
 {
 	const int grid = n_cu * wg_per_cu;
-	constexpr int NCV = WAVES / NCB, NBW = (NBF + NCB - 1) / NCB;
+	constexpr int NCV = WAVES / NCB, NBW = MISS ? 2 * NBF - 1 : (NBF + NCB - 1) / NCB;
 	const S3Plan pl = s3_plan(M, ntile, grid, NAF * NCV, bpv);
 	const size_t need = (size_t)pl.ng * pl.ipg * WAVES * NAF * NBW * 256;
 	if (need > out_ints) { fprintf(stderr, "%s: out buffer too small (%zu > %zu)\n", name, need, out_ints); exit(1); }
 	if (plan_out) *plan_out = pl;
 	const size_t lds = ((size_t)(DB + 1) * 4 * NBF + (size_t)(DA + 1) * NCV * NAF * (RM == 1 ? 2 : 1)) * 1024;
 	if (lds > 163840) { printf("%-40s skipped: %zu B of LDS\n", name, lds); return 0; }
-	auto kern = score3_kernel<NBF, NAF, WAVES, NLA, NLB, DA, DB, ABL, NCB, NBUF, RM>;
+	auto kern = score3_kernel<NBF, NAF, WAVES, NLA, NLB, DA, DB, ABL, NCB, NBUF, RM, MISS>;
 	static unsigned long long *stamps = nullptr;
 	if (!stamps) CK(hipMalloc((void **)&stamps, 16 * 4096));
 	CK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -79,7 +79,7 @@ static float run(const char *name, const uint8_t *A, const uint8_t *Fl, int ntil
 			if (!c.empty()) ghz = c[c.size() / 2];
 		}
 		printf("%-40s %s NBF=%2d NAF=%d NC=%d/%d NL=%d+%d D=%d/%d buf %d ABL=%2d  items/grp=%4d f=%2d  %7.3f ms  %6.0f GB/s  %.3f of 8 TB/s",
-			name, RM == 2 ? "lines" : RM ? "rows " : "tiles", NBF, NAF, WAVES, NCB, NLA, NLB, DA, DB, NBUF, ABL, pl.ipg, pl.f, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0);
+			name, MISS ? "rows3" : RM == 2 ? "lines" : RM ? "rows " : "tiles", NBF, NAF, WAVES, NCB, NLA, NLB, DA, DB, NBUF, ABL, pl.ipg, pl.f, best, bytes / best / 1e6, bytes / best / 1e6 / 8000.0);
 		if (ABL & 16) printf("  clock %.3f GHz", ghz);
 		printf("\n");
 		fflush(stdout);
@@ -88,7 +88,7 @@ static float run(const char *name, const uint8_t *A, const uint8_t *Fl, int ntil
 }
 
 // CPU check: sums of the item slabs per (variant, column) against the direct sum
-template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int NCB = 1, int NBUF = 2, int RM = 0>
+template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int NCB = 1, int NBUF = 2, int RM = 0, bool MISS = false>
 static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu, size_t row_pad = 0)
 {
 	const int ntile = 2 * ((N + 511) / 512);
@@ -138,13 +138,13 @@ static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu, siz
 	CK(hipMemcpy(dA, hA.data(), abytes_dev, hipMemcpyHostToDevice));
 	CK(hipMemcpy(dF, hF.data(), flbytes, hipMemcpyHostToDevice));
 	const int grid = n_cu * wg_per_cu;
-	constexpr int NCV = WAVES / NCB, NBW = (NBF + NCB - 1) / NCB;
+	constexpr int NCV = WAVES / NCB, NBW = MISS ? 2 * NBF - 1 : (NBF + NCB - 1) / NCB;
 	const S3Plan pl0 = s3_plan(M, ntile, grid, NAF * NCV);
 	const size_t oints = (size_t)pl0.ng * pl0.ipg * WAVES * NAF * NBW * 256;
 	CK(hipMalloc((void **)&dO, oints * 4));
 	CK(hipMemset(dO, 0xCD, oints * 4));
 	S3Plan pl;
-	run<NBF, NAF, WAVES, NLA, NLB, DA, DB, 0, NCB, NBUF, RM>(name, dA, dF, ntile, M, wg_per_cu, n_cu, dO, oints, 0, &pl, bpv);
+	run<NBF, NAF, WAVES, NLA, NLB, DA, DB, 0, NCB, NBUF, RM, MISS>(name, dA, dF, ntile, M, wg_per_cu, n_cu, dO, oints, 0, &pl, bpv);
 	std::vector<int> hO(oints);
 	CK(hipMemcpy(hO.data(), dO, oints * 4, hipMemcpyDeviceToHost));
 	long long bad = 0;
@@ -168,8 +168,25 @@ static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu, siz
 			}
 			if (got != ref) { if (bad < 5) fprintf(stderr, "%s: variant %zu col %d: got %lld want %lld\n", name, v, c, got, ref); bad++; }
 		}
+		// the missing plane against the value columns (slots NBF .. 2 NBF - 2 of the slab)
+		for (int c = 0; MISS && c < NCOL - 16; c++) {
+			long long ref = 0;
+			for (size_t s = 0; s < (size_t)ntile * 256; s++) {
+				const int cd = code[v * ntile * 256 + s];
+				const int t = (int)(s / 256), g16 = (int)(s % 256) / 16, e = (int)(s % 16);
+				ref += (long long)((cd == 3) * s3_scale(e)) * (int8_t)hF[((size_t)(t * 16 + g16) * NCOL + c) * 16 + s3_pos(e)];
+			}
+			long long got = 0;
+			for (int g = 0; g < pl.ng; g++) {
+				int first, count;
+				s3_items_of(pl, vtile, g, first, count);
+				for (int id = first; id < first + count; id++)
+					got += hO[(((size_t)id * WAVES + vg) * NAF + f) * NBW * 256 + (size_t)(NBF + c / 16) * 256 + reg * 64 + kg * 16 + (c % 16)];
+			}
+			if (got != ref) { if (bad < 5) fprintf(stderr, "%s: variant %zu missing-plane col %d: got %lld want %lld\n", name, v, c, got, ref); bad++; }
+		}
 	}
-	printf("check %s %-30s N=%d M=%zu ntile=%d ng=%d wpg=%d rf=%d rem=%d f=%d: %s\n", RM ? "rows " : "tiles", name, N, M, ntile, pl.ng, pl.wpg, pl.rf, pl.rem, pl.f, bad ? "FAILED" : "ok");
+	printf("check %s %-30s N=%d M=%zu ntile=%d ng=%d wpg=%d rf=%d rem=%d f=%d: %s\n", MISS ? "rows3" : RM ? "rows " : "tiles", name, N, M, ntile, pl.ng, pl.wpg, pl.rf, pl.rem, pl.f, bad ? "FAILED" : "ok");
 	CK(hipFree(dA)); CK(hipFree(dF)); CK(hipFree(dO));
 	return bad ? 1 : 0;
 }
@@ -289,6 +306,9 @@ int main(int argc, char **argv)
 #define CHKP(NBF, NAF, NC, NLA, NLB, DA, DB) bad += check<NBF, NAF, NC, NLA, NLB, DA, DB, 1, 2, 1>("product form", 2100 + 37 * NBF, 600 + NBF, 1, 8, (NBF & 1) * 64);
 		S3_FOR_EACH_NBF(CHKP)
 #undef CHKP
+#define CHKM(NBF, NAF, NC, NLA, NLB, DA, DB) bad += check<NBF, NAF, NC, NLA, NLB, DA, DB, 1, 2, 1, true>("three-plane form", 1900 + 41 * NBF, 500 + NBF, 1, 8, (NBF & 1) * 64);
+		S3_FOR_EACH_NBF_MISS(CHKM)
+#undef CHKM
 		return bad ? 1 : 0;
 	}
 	const int N = argc > 1 ? atoi(argv[1]) : 430000;
@@ -351,6 +371,15 @@ int main(int argc, char **argv)
 		R1(4, 2, 12, 3, 1, 1, 2, 0, "k3 naf2 12+3+1 pairs d1/2");
 		R1(4, 4, 8, 3, 1, 1, 1, 1, "k3 naf4 pairs d1/1 memory only");
 		R1(4, 3, 8, 3, 1, 1, 2, 1, "k3 naf3 pairs d1/2 memory only");
+#define R3M(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, name) run<NBF, NAF, NC, NLA, NLB, DA, DB, ABL, 1, 2, 1, true>(name, Ar, Fl, ntile, M, 1, n_cu, out, oints, reps, nullptr, bpv)
+		R3M(4, 2, 8, 3, 1, 2, 2, 0, "k3 three planes naf2 8+3+1 d2/2");
+		R3M(4, 2, 8, 3, 1, 2, 1, 0, "k3 three planes naf2 8+3+1 d2/1");
+		R3M(4, 2, 8, 2, 2, 2, 2, 0, "k3 three planes naf2 8+2+2 d2/2");
+		R3M(4, 4, 4, 3, 1, 2, 2, 0, "k3 three planes naf4 4+3+1 d2/2");
+		R3M(4, 2, 8, 3, 1, 2, 2, 1, "k3 three planes naf2 memory only");
+		R3M(2, 4, 8, 3, 1, 1, 2, 0, "quant three planes naf4");
+		R3M(6, 3, 4, 2, 2, 2, 1, 0, "k5 three planes naf3 4+2+2");
+		R3M(12, 1, 4, 2, 2, 2, 1, 0, "k13 three planes naf1 4+2+2");
 		R0(2, 4, 8, 3, 1, 3, 2, 0, "quant naf4 8+3+1 d3/2");
 		R1(2, 4, 8, 3, 1, 1, 2, 0, "quant naf4 8+3+1 pairs d1/2");
 		R1(2, 4, 8, 3, 1, 1, 3, 0, "quant naf4 8+3+1 pairs d1/3");
