@@ -50,7 +50,7 @@ struct S3Lists {
 	int nsub;              // sub-pools in use: min(S3_NSUB, workgroups of a full load), so that small blocks keep large sub-pools
 };
 
-// One wave per (variant v, sample range g): the range's 16-byte pieces (64 samples) are read with all lanes'
+// One wave per (variant v, sample range g), four variants of a range per workgroup: the range's 16-byte pieces (64 samples) are read with all lanes'
 // loads in flight at once (MAXLD uint4 per lane: 8 KiB per wave; a range of N = 430 000 is 6.6 KiB), the
 // missing codes counted, ONE atomic add reserves the segment, the lanes write their sample indices behind a
 // wave prefix (a lane's entries are contiguous: the segment is in lane order, not in sample order -- T3 does
@@ -67,14 +67,17 @@ s3_lists_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, int 
 	uint8_t *__restrict__ dst, size_t dst_bpv)
 {
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-	const long long w = (long long)blockIdx.x * 4 + wid;
-	if (w >= (long long)m * L.nr) return;
-	const int vl = (int)(w / L.nr), g = (int)(w % L.nr), v = v_first + vl;
+	// workgroup = (range g, four consecutive variants): its four segments are reserved by ONE atomic add and lie
+	// behind each other, so that a wave of the T3 pass (eight consecutive variants of a range) reads two runs
+	const int nq = (m + 3) / 4, g = (int)(blockIdx.x / nq), vl = (int)(blockIdx.x % nq) * 4 + wid, v = v_first + vl;
+	const bool live = vl < m;
 	const int t0 = s3_range_t0(g, ntile, L.nr), t1 = s3_range_t0(g + 1, ntile, L.nr);
-	const int npiece = (t1 - t0) * 4, p0 = t0 * 4;              // pieces of the range; first piece of the row
-	const uint8_t *src = rows + (size_t)vl * bpv + (size_t)t0 * 64;
-	uint8_t *out = COPY ? dst + (size_t)v * dst_bpv + (size_t)t0 * 64 : nullptr;
+	const int npiece = live ? (t1 - t0) * 4 : 0, p0 = t0 * 4;   // pieces of the range; first piece of the row
+	const uint8_t *src = rows + (size_t)(live ? vl : 0) * bpv + (size_t)t0 * 64;
+	uint8_t *out = COPY ? dst + (size_t)(live ? v : 0) * dst_bpv + (size_t)t0 * 64 : nullptr;
 	const size_t e = (size_t)g * L.ld + v;
+	__shared__ int sh_tot[4];
+	__shared__ unsigned sh_base;
 	const unsigned sub = blockIdx.x % (unsigned)L.nsub, subcap = L.idx_cap / (unsigned)L.nsub;
 	const bool tail = (p0 + npiece) * 64 > N;                   // (wave-uniform) the range reaches past the last sample
 	// the piece with the samples >= N cleared
@@ -105,15 +108,30 @@ s3_lists_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, int 
 			c2 += __popc(~d[u] & (d[u] >> 1) & 0x55555555u);
 		}
 	};
+	// the workgroup's four segments in one reservation (every wave of the workgroup gets here)
 	auto reserve = [&](int tot, unsigned &start) -> bool {
-		start = 0;
-		if (tot > 0) {
-			if (lane == 0) start = atomicAdd(L.cursor + (size_t)sub * S3_CURSOR_STRIDE, (unsigned)tot);
-			start = (unsigned)__builtin_amdgcn_readfirstlane((int)start);
+		if (lane == 0) sh_tot[wid] = tot;
+		__syncthreads();
+		const int all = sh_tot[0] + sh_tot[1] + sh_tot[2] + sh_tot[3];
+		// (a workgroup that holds a row of missing codes would take its three neighbours down with it: beyond an
+		// eighth of the sub-pool every wave reserves for itself)
+		const bool together = (unsigned)all <= subcap / 8;
+		if (threadIdx.x == 0) sh_base = (together && all > 0) ? atomicAdd(L.cursor + (size_t)sub * S3_CURSOR_STRIDE, (unsigned)all) : 0u;
+		__syncthreads();
+		unsigned base = sh_base;
+		bool ok;
+		if (together) {
+			ok = (unsigned long long)base + (unsigned long long)all <= (unsigned long long)subcap;
+			start = sub * subcap + base + (unsigned)((wid > 0 ? sh_tot[0] : 0) + (wid > 1 ? sh_tot[1] : 0) + (wid > 2 ? sh_tot[2] : 0));
+		} else {
+			base = 0;
+			const bool fits = (unsigned)tot <= subcap;          // (a segment larger than the sub-pool does not touch the cursor)
+			if (lane == 0 && tot > 0 && fits) base = atomicAdd(L.cursor + (size_t)sub * S3_CURSOR_STRIDE, (unsigned)tot);
+			base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+			ok = fits && (unsigned long long)base + (unsigned long long)tot <= (unsigned long long)subcap;
+			start = sub * subcap + base;
 		}
-		const bool ok = (unsigned long long)start + (unsigned long long)tot <= (unsigned long long)subcap;
-		start += sub * subcap;
-		if (lane == 0) { L.lstart[e] = ok ? start : 0u; L.lcnt[e] = ok ? tot : -1; }
+		if (lane == 0 && live) { L.lstart[e] = ok ? start : 0u; L.lcnt[e] = ok ? tot : -1; }
 		return ok && tot > 0;
 	};
 	if (npiece <= MAXLD * 64) {
@@ -135,7 +153,7 @@ s3_lists_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, int 
 		if (COUNTS) {
 			cz = __builtin_amdgcn_readlane(lst_scan_incl(cz), 63);
 			c2 = __builtin_amdgcn_readlane(lst_scan_incl(c2), 63);
-			if (lane == 0) { L.nzp[e] = cz; L.n2p[e] = c2; }
+			if (lane == 0 && live) { L.nzp[e] = cz; L.n2p[e] = c2; }
 		}
 		unsigned start;
 		if (!reserve(tot, start)) return;
@@ -158,13 +176,107 @@ s3_lists_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, int 
 	if (COUNTS) {
 		cz = __builtin_amdgcn_readlane(lst_scan_incl(cz), 63);
 		c2 = __builtin_amdgcn_readlane(lst_scan_incl(c2), 63);
-		if (lane == 0) { L.nzp[e] = cz; L.n2p[e] = c2; }
+		if (lane == 0 && live) { L.nzp[e] = cz; L.n2p[e] = c2; }
 	}
 	unsigned start;
 	if (!reserve(tot, start)) return;
 	unsigned o = start + (unsigned)(incl - c);
 	for (int p = lane; p < npiece; p += 64)
 		o = emit(miss64(clip(*reinterpret_cast<const uint4 *>(src + (size_t)p * 16), p)), p, o);
+}
+
+// The row-major call's form of the two kernels (list pass + sparse T3 pass) in one: the wave that finds the missing
+// genotypes of (variant v, range g) does not list them in global memory but compacts them into its 1 KiB of LDS
+// and gathers their rows of Q right away (PP lanes per entry, the columns; 64 / PP entries per step), so that the
+// rows are still read once, the sparse sums cost the gathers' latency under the stream instead of a kernel of
+// their own (0.33 ms at N = 430 000), and no pool is needed.  part[g][v][c] = {hi, lo} as s3_t3_kernel leaves them;
+// lcnt[g][v] = the count, or -1 when the segment holds more than S3_LT_CAP entries (the variant then takes the
+// FP64 kernel; a block with that many missing genotypes is the three-plane form's business).
+#define S3_LT_CAP 256
+template <int MAXLD, int PP>
+__global__ void __launch_bounds__(256)
+s3_lists_t3_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, int ntile, S3Lists L,
+	int P, const long long *__restrict__ Q, long long *__restrict__ part)
+{
+	constexpr int TPE = 64 / PP;
+	__shared__ unsigned ent[4][S3_LT_CAP];
+	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+	const int nq = (m + 3) / 4, g = (int)(blockIdx.x / nq), v = (int)(blockIdx.x % nq) * 4 + wid;
+	if (v >= m) return;                                        // (no workgroup barrier below)
+	const int t0 = s3_range_t0(g, ntile, L.nr), t1 = s3_range_t0(g + 1, ntile, L.nr);
+	const int npiece = (t1 - t0) * 4, p0 = t0 * 4;
+	const uint8_t *src = rows + (size_t)v * bpv + (size_t)t0 * 64;
+	const size_t e = (size_t)g * L.ld + v;
+	const bool tail = (p0 + npiece) * 64 > N;
+	auto clip = [&](uint4 wv, int p) -> uint4 {
+		if (!tail) return wv;
+		const int k0 = N - (p0 + p) * 64;
+		return make_uint4(wv.x & lst_keep(k0), wv.y & lst_keep(k0 - 16), wv.z & lst_keep(k0 - 32), wv.w & lst_keep(k0 - 48));
+	};
+	auto miss64 = [&](const uint4 &wv) -> unsigned long long {
+		const uint32_t a = wv.x & (wv.x >> 1) & 0x55555555u, b = wv.y & (wv.y >> 1) & 0x55555555u;
+		const uint32_t c = wv.z & (wv.z >> 1) & 0x55555555u, d = wv.w & (wv.w >> 1) & 0x55555555u;
+		return ((unsigned long long)(c | (d << 1)) << 32) | (a | (b << 1));
+	};
+	auto emit = [&](unsigned long long mm, int p, int o) -> int {
+		while (mm) {
+			const int b = __ffsll((long long)mm) - 1;
+			mm &= mm - 1;
+			if (o < S3_LT_CAP) ent[wid][o] = (unsigned)((p0 + p) * 64 + (b >> 5) * 32 + (b & 1) * 16 + ((b & 31) >> 1));
+			o++;
+		}
+		return o;
+	};
+	int tot = 0;
+	if (npiece <= MAXLD * 64) {
+		unsigned long long mk[MAXLD];
+		int c = 0;
+#pragma unroll
+		for (int k = 0; k < MAXLD; k++) {
+			const int p = k * 64 + lane;
+			uint4 wv = make_uint4(0u, 0u, 0u, 0u);
+			if (p < npiece) wv = *reinterpret_cast<const uint4 *>(src + (size_t)p * 16);
+			mk[k] = miss64(clip(wv, p));
+			c += __popcll(mk[k]);
+		}
+		const int incl = lst_scan_incl(c);
+		tot = __builtin_amdgcn_readlane(incl, 63);
+		int o = incl - c;
+#pragma unroll
+		for (int k = 0; k < MAXLD; k++) o = emit(mk[k], k * 64 + lane, o);
+	} else {
+		for (int pb = 0; pb < npiece; pb += 64) {             // (wave-uniform bounds)
+			const int p = pb + lane;
+			uint4 wv = make_uint4(0u, 0u, 0u, 0u);
+			if (p < npiece) wv = *reinterpret_cast<const uint4 *>(src + (size_t)p * 16);
+			const unsigned long long mm = miss64(clip(wv, p));
+			const int c = __popcll(mm), incl = lst_scan_incl(c);
+			emit(mm, p, tot + incl - c);
+			tot += __builtin_amdgcn_readlane(incl, 63);
+		}
+	}
+	const bool ok = tot <= S3_LT_CAP;
+	if (lane == 0) L.lcnt[e] = ok ? tot : -1;
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave's own LDS writes, in order
+	__builtin_amdgcn_wave_barrier();
+	const int c = lane % PP, t = lane / PP;
+	long long hi = 0, lo = 0;
+	if (ok) {
+#pragma unroll 4
+		for (int eb = 0; eb < tot; eb += TPE) {
+			const int ei = eb + t;
+			if (ei < tot && c < P) {
+				const long long q = Q[(size_t)ent[wid][ei] * P + c];
+				hi += q >> 32; lo += q & 0xFFFFFFFFll;
+			}
+		}
+	}
+#pragma unroll
+	for (int o = PP; o < 64; o <<= 1) { hi += __shfl_xor(hi, o, 64); lo += __shfl_xor(lo, o, 64); }
+	if (t == 0 && c < P) {
+		long long *o = part + (((size_t)g * m + v) * P + c) * 2;
+		o[0] = hi; o[1] = lo;
+	}
 }
 
 // per variant: n3 = its listed missing genotypes, ovf = 1 when a range found the pool full; with the carrier

@@ -144,7 +144,9 @@ struct sgx_handle {
 	int *s3_ovf = nullptr; size_t s3_ovf_cap = 0;
 	bool s3_attr[17] = {false};       // per NBF: dynamic LDS size raised
 	bool s3_attr_miss[17] = {false};  // ... of the three-plane form
-	hipStream_t s3_side = nullptr;    // the sparse pass over the missing genotypes runs beside the contraction kernel
+	hipStream_t hstream = nullptr;    // the score chain of a block scan (list pass, sparse pass, contraction, reduction, epilogue): HIGH priority,
+	                                  // so that it is not slowed by the SPA kernels of the other lane's step it runs beside (h->stream: low)
+	hipStream_t s3_side = nullptr;    // the sparse pass over the missing genotypes (beside the list pass's tail; joined before the contraction kernel)
 	hipEvent_t s3_fork = nullptr, s3_join = nullptr;
 	sgx_block *tmp_blk[2] = {nullptr, nullptr};   // row-major calls: the rows are ingested into a block first
 	int n_cu = 256;
@@ -317,8 +319,16 @@ static bool fit_xvx_inverse(const sgx_model *m, double *out)
 static int alloc_workspace(sgx_handle *h)
 {
 	const int N = h->md.N;
-	HIPCHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-	HIPCHK(hipStreamCreateWithFlags(&h->s3_side, hipStreamNonBlocking));
+	{
+		// The step's critical path is the score chain (it streams the genotypes; the next step's chain cannot start
+		// before this one's ends), the SPA stage hides under the other lane's chain: two priorities (round 4: kernel
+		// traces showed the list pass stretched from 0.98 to 1.44 ms and 20-us solve kernels waiting 0.7 ms behind it)
+		int least = 0, greatest = 0;
+		HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+		HIPCHK(hipStreamCreateWithPriority(&h->stream, hipStreamNonBlocking, least));
+		HIPCHK(hipStreamCreateWithPriority(&h->hstream, hipStreamNonBlocking, greatest));
+		HIPCHK(hipStreamCreateWithPriority(&h->s3_side, hipStreamNonBlocking, greatest));
+	}
 	HIPCHK(hipEventCreateWithFlags(&h->s3_fork, hipEventDisableTiming));
 	HIPCHK(hipEventCreateWithFlags(&h->s3_join, hipEventDisableTiming));
 	HIPCHK(hipMalloc((void **)&h->counters, 24 * sizeof(int)));
@@ -606,6 +616,7 @@ extern "C" void sgx_free(sgx_handle *h)
 	for (int i = 0; i < 2; i++) if (h->evk[i]) (void)hipEventDestroy(h->evk[i]);
 	if (h->ev_lists) (void)hipEventDestroy(h->ev_lists);
 	if (h->s3_side) { (void)hipStreamSynchronize(h->s3_side); (void)hipStreamDestroy(h->s3_side); }
+	if (h->hstream) { (void)hipStreamSynchronize(h->hstream); (void)hipStreamDestroy(h->hstream); }
 	if (h->s3_fork) (void)hipEventDestroy(h->s3_fork);
 	if (h->s3_join) (void)hipEventDestroy(h->s3_join);
 	if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1041,15 +1052,15 @@ static int block_create(int32_t n_samp, size_t max_variants, int device, bool li
 	b->device = device; b->N = n_samp; b->ntile = 2 * ((n_samp + 511) / 512); b->nr = s3_nranges(b->ntile); b->cap = max_variants;
 	b->lists_only = lists_only;
 	b->bpv = (size_t)b->ntile * 64;
-	b->idx_cap = block_idx_cap(n_samp, max_variants);
+	b->idx_cap = lists_only ? 0 : block_idx_cap(n_samp, max_variants);    // (the row-major calls gather on the spot: no pool)
 	b->cidx_cap = lists_only ? 0 : block_cidx_cap(n_samp, max_variants, cavg);
 	const size_t nrc = (size_t)b->nr * max_variants;
 	hipError_t e = hipSetDevice(device);
 	if (e == hipSuccess && !lists_only) e = hipMalloc((void **)&b->rows, max_variants * b->bpv);
-	if (e == hipSuccess) e = hipMalloc((void **)&b->idx, b->idx_cap * sizeof(unsigned));
+	if (e == hipSuccess && !lists_only) e = hipMalloc((void **)&b->idx, b->idx_cap * sizeof(unsigned));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->cursor, (size_t)S3_NSUB * S3_CURSOR_STRIDE * sizeof(unsigned));
 	if (e == hipSuccess) e = hipMemset(b->cursor, 0, (size_t)S3_NSUB * S3_CURSOR_STRIDE * sizeof(unsigned));
-	if (e == hipSuccess) e = hipMalloc((void **)&b->lstart, nrc * sizeof(unsigned));
+	if (e == hipSuccess && !lists_only) e = hipMalloc((void **)&b->lstart, nrc * sizeof(unsigned));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->lcnt, nrc * sizeof(int));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->n3, max_variants * sizeof(int));
 	if (e == hipSuccess) e = hipMalloc((void **)&b->ovf, max_variants);
@@ -1105,7 +1116,7 @@ static RowsRef block_rows(const sgx_block *b)
 // block_finish once
 static int block_put_rows(sgx_block *b, const uint8_t *rows_dev, size_t bpv, size_t v_first, size_t m, hipStream_t st)
 {
-	const unsigned grid = (unsigned)((m * (size_t)b->nr + 3) / 4);
+	const unsigned grid = (unsigned)(((m + 3) / 4) * (size_t)b->nr);
 	const S3Lists L = block_lists(b);
 	if (b->lists_only)
 		hipLaunchKernelGGL((s3_lists_kernel<8, false, false>), dim3(grid), dim3(256), 0, st, rows_dev, bpv, b->N, (int)m, (int)v_first, b->ntile, L,
@@ -1184,6 +1195,7 @@ static int ensure_buf(sgx_handle *h, T **p, size_t *cap, size_t need)
 {
 	if (need <= *cap) return SGX_OK;
 	HIPCHK(hipStreamSynchronize(h->stream));
+	if (h->hstream) HIPCHK(hipStreamSynchronize(h->hstream));
 	if (h->s3_side) HIPCHK(hipStreamSynchronize(h->s3_side));
 	if (*p) HIPCHK(hipFree(*p));
 	*p = nullptr; *cap = 0;
@@ -1197,11 +1209,13 @@ static int ensure_buf(sgx_handle *h, T **p, size_t *cap, size_t need)
 // cover, SPA stage.
 // miss: the three-plane form -- the sums over the missing samples come out of the contraction kernel, the block's lists
 // are not read (and need not exist)
-static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double *out8, uint8_t *valid, bool lazy_dense = false, bool miss = false)
+// t3_done: the per-range sums over the missing samples are in h->s3_t3 already (scan_rows_dev's fused list + T3 pass)
+static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double *out8, uint8_t *valid, bool lazy_dense = false, bool miss = false,
+	bool t3_done = false)
 {
 	const DevModel &md = h->md;
 	const MfEpi &ep = h->mfe;
-	hipStream_t st = h->stream;
+	hipStream_t st = h->hstream;
 	const int NBF = h->mf_nbfv[0] + 1;
 	const int grid = std::max(8, h->n_cu & ~7);
 	const RowsRef rr = block_rows(b);
@@ -1250,6 +1264,11 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	//  * launched together onto an idle GPU the pass's 25 000 small workgroups and the kernel's 256 persistent ones
 	//    fight for the CUs (kernel traces: 1.9 ms for the kernel and 1.1 ms for the pass in those steps).
 	// (round 3, tools/README.md: the three orders measured)
+	if (t3_done) {
+		const size_t n3e = M * (size_t)md.P * 2;
+		hipLaunchKernelGGL(s3_t3_sum_kernel, dim3((unsigned)((n3e + 255) / 256)), dim3(256), 0, st, n3e, b->nr, h->s3_t3, h->s3_t3 + (size_t)b->nr * n3e);
+		HIPCHK(hipGetLastError());
+	} else {
 	HIPCHK(hipEventRecord(h->s3_fork, st));                  // (the side stream starts where this stream stands NOW)
 	HIPCHK(hipStreamWaitEvent(h->s3_side, h->s3_fork, 0));
 	{
@@ -1268,6 +1287,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 		HIPCHK(hipEventRecord(h->s3_join, s2));
 	}
 	HIPCHK(hipStreamWaitEvent(st, h->s3_join, 0));
+	}
 	switch (NBF) {
 #define S3CASE(NBF_, NAF_, NC_, NLA_, NLB_, DA_, DB_)                                                         \
 	case NBF_: {                                                                                          \
@@ -1314,6 +1334,8 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[1], st));
 	h->stats.score_launches = 6;
+	st = h->stream;                                  // the SPA stage: low priority, behind the score chain
+	HIPCHK(hipStreamWaitEvent(st, h->ev[1], 0));
 	rc = launch_spa<IN_2BIT>(h, rr, M, out8, lazy_dense);
 	if (rc) return rc;
 	if (lazy_dense) h->pend_dense.blk = b;
@@ -1341,7 +1363,7 @@ static int next_lane(sgx_handle *h, size_t M, sgx_handle **lane_out)
 	rc = ensure_recs(lane, M);
 	if (rc) return rc;
 	// score stages do not overlap: this one starts after the other lane's has ended
-	if (other && other != lane && other->stats_pending) HIPCHK(hipStreamWaitEvent(lane->stream, other->ev[1], 0));
+	if (other && other != lane && other->stats_pending) HIPCHK(hipStreamWaitEvent(lane->hstream, other->ev[1], 0));
 	*lane_out = lane;
 	return SGX_OK;
 }
@@ -1418,6 +1440,7 @@ static int ensure_tmp_block(sgx_handle *lane, int which, size_t M)
 	sgx_block *&tb = lane->tmp_blk[which];
 	if (tb && tb->cap >= M) return SGX_OK;
 	HIPCHK(hipStreamSynchronize(lane->stream));
+	HIPCHK(hipStreamSynchronize(lane->hstream));
 	if (tb) { sgx_block_free(tb); tb = nullptr; }
 	return block_create(lane->md.N, M, lane->device, true, 0, &tb);
 }
@@ -1431,13 +1454,27 @@ static int scan_rows_dev(sgx_handle *lane, int which, const uint8_t *rows_dev, s
 	sgx_block *tb = lane->tmp_blk[which];
 	tb->ext_rows = rows_dev; tb->ext_bpv = bpv;
 	if (rows_take_three_planes(lane)) return launch_block_scan(lane, tb, M, out8, valid, lazy_dense, true);
-	HIPCHK(hipEventRecord(lane->ev_lists, lane->stream));
-	lane->lists_timed = true;
-	rc = block_put_rows(tb, rows_dev, bpv, 0, M, lane->stream);
-	if (!rc) rc = block_finish(tb, M, lane->stream);
+	// one pass over the rows: the missing genotypes of every (range, variant), their sums of Q gathered on the spot
+	rc = ensure_buf(lane, &lane->s3_t3, &lane->s3_t3_cap, (size_t)(tb->nr + 1) * M * lane->md.P * 2);
 	if (rc) return rc;
-	return launch_block_scan(lane, tb, M, out8, valid, lazy_dense);
+	HIPCHK(hipEventRecord(lane->ev_lists, lane->hstream));
+	lane->lists_timed = true;
+	{
+		const S3Lists L = block_lists(tb);
+		const int P = lane->md.P, PP = P <= 8 ? 8 : P <= 16 ? 16 : P <= 32 ? 32 : 64;
+		const dim3 grid((unsigned)(((M + 3) / 4) * (size_t)tb->nr));
+		hipStream_t st = lane->hstream;
+		if (PP == 8) hipLaunchKernelGGL((s3_lists_t3_kernel<8, 8>), grid, dim3(256), 0, st, rows_dev, bpv, tb->N, (int)M, tb->ntile, L, P, lane->dQ, lane->s3_t3);
+		else if (PP == 16) hipLaunchKernelGGL((s3_lists_t3_kernel<8, 16>), grid, dim3(256), 0, st, rows_dev, bpv, tb->N, (int)M, tb->ntile, L, P, lane->dQ, lane->s3_t3);
+		else if (PP == 32) hipLaunchKernelGGL((s3_lists_t3_kernel<8, 32>), grid, dim3(256), 0, st, rows_dev, bpv, tb->N, (int)M, tb->ntile, L, P, lane->dQ, lane->s3_t3);
+		else hipLaunchKernelGGL((s3_lists_t3_kernel<8, 64>), grid, dim3(256), 0, st, rows_dev, bpv, tb->N, (int)M, tb->ntile, L, P, lane->dQ, lane->s3_t3);
+		HIPCHK(hipGetLastError());
+	}
+	rc = block_finish(tb, M, lane->hstream);
+	if (rc) return rc;
+	return launch_block_scan(lane, tb, M, out8, valid, lazy_dense, false, true);
 }
+
 
 extern "C" int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev, size_t bpv,
 	size_t M, double *out8_dev, uint8_t *valid_dev)
@@ -1618,6 +1655,7 @@ static int scan_host(sgx_handle *h, const void *rows, size_t src_row_bytes, size
 		// the COMPUTE stream: on the copy stream the 2.5 ms of ingest sat between two 9.5-ms copies and the
 		// link idled a fifth of the time (43 GB/s; the next copy now starts as this one ends).
 		HIPCHK(hipStreamWaitEvent(h->stream, h->ev_h2d, 0));
+		HIPCHK(hipStreamWaitEvent(h->hstream, h->ev_h2d, 0));
 		if (as_block) rc = scan_rows_dev(h, b, INPUT == IN_2BIT ? h->pipe_in[b] : h->pipe_pk[b], INPUT == IN_2BIT ? dev_row_bytes : pk_row, m,
 			h->pipe_out[b], h->pipe_valid[b], false);
 		else if (INPUT == IN_2BIT) rc = launch_scan<IN_2BIT>(h, h->pipe_in[b], dev_row_bytes, m, h->pipe_out[b], h->pipe_valid[b]);

@@ -204,7 +204,7 @@ static int lists_bench(const uint8_t *rows, size_t bpv, int N, size_t M, int nti
 	uint8_t *copy = nullptr;
 	CK(hipMalloc((void **)&copy, M * bpv));
 	hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-	const unsigned grid = (unsigned)((M * (size_t)L.nr + 3) / 4);
+	const unsigned grid = (unsigned)(((M + 3) / 4) * (size_t)L.nr);
 	for (int mode = 0; mode < 2; mode++) {
 		float best = 1e30f;
 		for (int r = 0; r < reps + 1; r++) {
