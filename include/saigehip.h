@@ -116,6 +116,8 @@ typedef struct sgx_stats {
 	                          missing samples from a third MFMA plane: no lists, no sparse pass; chosen for
 	                          few score columns or many missing genotypes); totals: number of such calls     */
 	uint32_t n_unlisted;   /* variants whose missing genotypes found the pool of the lists full (FP64 kernel)  */
+	uint32_t n_guarded;    /* variants whose a-posteriori bound on the fixed-point columns' quantisation (its
+	                          effect on the z-score) exceeded the guard: scored by the FP64 kernel  */
 } sgx_stats;
 
 /* Library / device ------------------------------------------------------- */
@@ -246,7 +248,8 @@ int sgx_geno_stats_2bit(const uint8_t *packed, size_t bytes_per_variant, int32_t
  * sgx_sync() before reading any output), "pipe_mb" (MiB of input rows per chunk of a host-buffer scan;
  * 0 = default 512), "spa_abl" (diagnostic bits; 512: the SPA kernels scan the rows of a block instead of
  * walking its carrier lists), "three_plane" (-1 automatic, 0 / 1: never / always the three-plane form of the
- * contraction kernel).  Results never depend on them beyond rounding (1e-12). */
+ * contraction kernel), "guard_exp" (x: the fixed-point guard at 10^-x instead of 2e-11; 0 = off, 300 = every
+ * variant through the FP64 kernel).  Results never depend on them beyond rounding (1e-12). */
 int sgx_set_option(sgx_handle *h, const char *name, long long value);
 
 int sgx_sync(sgx_handle *h);

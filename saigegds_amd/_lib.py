@@ -45,7 +45,7 @@ class SgxStats(C.Structure):
         ("n_spa_dense", C.c_uint64), ("n_spa_slow", C.c_uint64),
         ("ms_score", C.c_float), ("ms_spa", C.c_float), ("ms_total", C.c_float),
         ("score_launches", C.c_uint32), ("spa_launches", C.c_uint32), ("ms_kernel", C.c_float),
-        ("ms_lists", C.c_float), ("three_plane", C.c_uint32), ("n_unlisted", C.c_uint32),
+        ("ms_lists", C.c_float), ("three_plane", C.c_uint32), ("n_unlisted", C.c_uint32), ("n_guarded", C.c_uint32),
     ]
 
     def as_dict(self):

@@ -193,6 +193,9 @@ struct sgx_handle {
 	// its genotypes as missing (or overflowed the pool), cleared when a three-plane step counted fewer than SGX_DENSE_OFF
 	bool dense_mode = false;
 	int dense_opt = -1;               // "three_plane" option: -1 automatic, 0 never, 1 always
+	// bound on the z-score's move by the fixed-point columns' quantisation beyond which a variant is scored by the FP64
+	// kernel (score3_epilogue): 2e-11 keeps the p-value inside 1e-10 relative with room; "guard_exp" option: 10^-x
+	double guard_tol = 2e-11;
 	bool used_miss = false;           // this lane's call in flight took the three-plane form
 	int next_lane = 0;                // primary: which lane takes the next _dev call
 	sgx_handle *last_issued = nullptr;// primary: lane of the most recent call
@@ -880,6 +883,7 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 	else if (n == "spa_exact") h->force_exact = value != 0;
 	else if (n == "pipe_mb") { if (value < 0 || value > 65536) return fail(SGX_EINVAL, "pipe_mb out of range"); h->pipe_bytes = (size_t)value << 20; return SGX_OK; }
 	else if (n == "spa_abl") h->spa_abl = (int)value;
+	else if (n == "guard_exp") { if (value < 0 || value > 300) return fail(SGX_EINVAL, "guard_exp must be 0..300"); h->guard_tol = std::pow(10.0, -(double)value); }
 	else if (n == "three_plane") { if (value < -1 || value > 1) return fail(SGX_EINVAL, "three_plane must be -1 (automatic), 0 or 1"); h->dense_opt = (int)value; return SGX_OK; }
 	else if (n == "lanes") {
 		if (value < 1 || value > 4) return fail(SGX_EINVAL, "lanes must be 1..4");
@@ -895,7 +899,7 @@ extern "C" int sgx_set_option(sgx_handle *h, const char *name, long long value)
 			t->dF = h->dF; t->dX = h->dX; t->dy = h->dy; t->dmu = h->dmu; t->dmu2 = h->dmu2; t->dXM = h->dXM; t->dFl = h->dFl; t->dQ = h->dQ;
 			t->shares_model = true; t->owner = h;
 			t->force_dense = h->force_dense; t->force_v1 = h->force_v1; t->force_exact = h->force_exact;
-			t->spa_abl = h->spa_abl;
+			t->spa_abl = h->spa_abl; t->guard_tol = h->guard_tol;
 			rc = set_dev(t);
 			if (!rc) rc = alloc_workspace(t);
 			if (rc) { sgx_free(t); return rc; }
@@ -929,12 +933,13 @@ static int sync_lane(sgx_handle *h)
 		h->stats.n_spa_dense = (uint64_t)h->h_counters[2];
 		h->stats.n_spa_slow = (uint64_t)h->h_counters[4];
 		h->stats.three_plane = h->used_miss ? 1u : 0u;
-		h->stats.n_unlisted = (uint32_t)h->h_counters[23];
+		h->stats.n_guarded = (uint32_t)h->h_counters[21];
+		h->stats.n_unlisted = (uint32_t)h->h_counters[23] - h->stats.n_guarded;
 		{
 			// the step's missing genotypes (census of the epilogue, units of 64) decide the form of the NEXT row-major calls
 			sgx_handle *p = h->owner ? h->owner : h;
 			const double frac = 64.0 * (double)h->h_counters[22] / ((double)std::max<uint64_t>(1, h->stats.n_variants) * (double)h->md.N);
-			const bool over = (uint64_t)h->h_counters[23] * 32 > h->stats.n_variants;
+			const bool over = (uint64_t)h->stats.n_unlisted * 32 > h->stats.n_variants;
 			if (!h->used_miss && (frac > SGX_DENSE_ON || over)) p->dense_mode = true;
 			else if (h->used_miss && frac < SGX_DENSE_OFF) p->dense_mode = false;
 		}
@@ -964,7 +969,7 @@ static int sync_lane(sgx_handle *h)
 		p->total.ms_score += x.ms_score; p->total.ms_spa += x.ms_spa; p->total.ms_total += x.ms_total; p->total.ms_kernel += x.ms_kernel;
 		p->total.ms_lists += x.ms_lists;
 		p->total.score_launches += x.score_launches; p->total.spa_launches += x.spa_launches;
-		p->total.three_plane += x.three_plane; p->total.n_unlisted += x.n_unlisted;
+		p->total.three_plane += x.three_plane; p->total.n_unlisted += x.n_unlisted; p->total.n_guarded += x.n_guarded;
 		p->total_calls++;
 	}
 	return SGX_OK;
@@ -1323,8 +1328,8 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	switch (md.K) {
 #define ECASE(KK) case KK:                                                                     \
 	hipLaunchKernelGGL((score3_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, md, ep, h->mf_acc, acc_stride, \
-		miss ? 16 * NBF : 0, h->s3_t3 + (size_t)b->nr * M * md.P * 2, b->n3, b->ovf, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid); \
-	if (!miss) hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, 256>), dim3((unsigned)std::min<size_t>(M, 4 * (size_t)h->n_cu)), dim3(256), 0, st, \
+		miss ? 16 * NBF : 0, h->s3_t3 + (size_t)b->nr * M * md.P * 2, b->n3, b->ovf, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid, h->guard_tol); \
+	hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, 256>), dim3((unsigned)std::min<size_t>(M, 4 * (size_t)h->n_cu)), dim3(256), 0, st, \
 		rr, (int)M, md, h->recs, h->counters, out8, valid, (const int *)h->s3_ovf, 23, btop, h->fb_spa2, h->fb_x2); \
 	break;
 	FOR_EACH_K(ECASE)
@@ -1608,7 +1613,7 @@ static int scan_host(sgx_handle *h, const void *rows, size_t src_row_bytes, size
 		total.ms_score += x.ms_score; total.ms_spa += x.ms_spa; total.ms_total += x.ms_total;
 		total.ms_kernel += x.ms_kernel; total.ms_lists += x.ms_lists;
 		total.score_launches += x.score_launches; total.spa_launches += x.spa_launches;
-		total.three_plane = std::max(total.three_plane, x.three_plane); total.n_unlisted += x.n_unlisted;      // (any chunk)
+		total.three_plane = std::max(total.three_plane, x.three_plane); total.n_unlisted += x.n_unlisted; total.n_guarded += x.n_guarded;   // (any chunk)
 		return SGX_OK;
 	};
 	size_t prev_off = 0, prev_m = 0;

@@ -43,6 +43,22 @@ def test_quant_golden(grm1k, model_quant, golden_quant):
     assert np.isnan(out[:, 6:]).all()
 
 
+def test_readme_dosage_file_pin():
+    """The reference's printed output for assoc_100snp.gds at mac = 10 (README.md:111-129): 38 survivors; ids 4, 12, 14
+    with AF.alt 0.0100 / 0.0150 / 0.0375, mac 20 / 30 / 75, num 1000 (the model of that session is not stored, so its
+    beta / SE / pval are not a pin; AF, mac, num and the filter do not depend on the model)."""
+    import os
+    from conftest import GOLDEN, scan_model
+    z = np.load(os.path.join(GOLDEN, "assoc_100snp.npz"))
+    sm = scan_model("saige_model.npz", mac=10, sample_ids=[str(s) for s in z["sample_id"]])
+    for out, valid in (Oracle(sm).scan_f64(z["dosage_u8"].astype(np.float64)), Oracle(sm).scan_u8(z["dosage_u8"])):
+        keep = np.flatnonzero(valid)
+        assert keep.size == 38
+        assert [int(x) for x in z["variant_id"][keep[:3]]] == [4, 12, 14]
+        np.testing.assert_allclose(out[keep[:3], 0], [0.0100, 0.0150, 0.0375], rtol=0, atol=1e-15)
+        assert np.array_equal(out[keep[:3], 1], [20.0, 30.0, 75.0]) and np.array_equal(out[keep[:3], 2], [1000.0] * 3)
+
+
 def test_input_types_agree(grm1k, model_bin):
     """RAW / REAL / 2-bit inputs of get_ds (saige_main.cpp:162-186) give one answer."""
     from saigegds_amd.gds import unpack_dosage_2bit
