@@ -404,6 +404,10 @@ def decode_dbit2(alleles, bit0: int, n_samp: int, m: int, out: np.ndarray, sel: 
     a = np.frombuffer(alleles, dtype=np.uint8) if not isinstance(alleles, np.ndarray) else alleles
     if out.dtype != np.uint8 or out.ndim != 2 or out.strides[1] != 1 or out.shape[0] < m:
         raise ValueError("decode_dbit2: out must be a [>= m, stride] uint8 array with contiguous rows")
+    if out.strides[0] != out.shape[1]:
+        # (the library zeroes a row's bytes from the last code up to its stride: a column slice of a wider buffer
+        # would have the neighbouring columns cleared, and the last row would be written past the allocation)
+        raise ValueError("decode_dbit2: out must own whole rows (a column slice of a wider buffer is not accepted)")
     need = (bit0 + m * n_samp * 4 + 7) // 8
     if a.size < need:
         raise ValueError("decode_dbit2: allele buffer too short")

@@ -630,41 +630,52 @@ def _packed_real16(raw: np.ndarray, cls: str, scale: float, offset: float) -> np
 
 
 def lz4_block_decode(src: bytes, raw_size: Optional[int] = None) -> bytes:
-    """LZ4 block format (sequences of literals + matches), pure Python: the test-sized streams only."""
+    """LZ4 block format (sequences of literals + matches), pure Python.  Matches are copied by slices (an
+    overlapping match -- the format's run-length trick -- by doubling); a block cut off inside a sequence is a
+    GdsError.  Parity unpinned: the reference holds no LZ4_RA file (README)."""
     out = bytearray()
     i, n = 0, len(src)
-    while i < n:
-        tok = src[i]
-        i += 1
-        ll = tok >> 4
-        if ll == 15:
-            while True:
-                c = src[i]
-                i += 1
-                ll += c
-                if c != 255:
-                    break
-        out += src[i:i + ll]
-        i += ll
-        if i >= n:
-            break
-        off = src[i] | (src[i + 1] << 8)
-        i += 2
-        if off == 0:
-            raise GdsError("LZ4: zero offset")
-        ml = (tok & 15) + 4
-        if (tok & 15) == 15:
-            while True:
-                c = src[i]
-                i += 1
-                ml += c
-                if c != 255:
-                    break
-        st = len(out) - off
-        if st < 0:
-            raise GdsError("LZ4: offset before the start of the block")
-        for k in range(ml):                 # overlapping copies are the format's run-length trick
-            out.append(out[st + k])
+    try:
+        while i < n:
+            tok = src[i]
+            i += 1
+            ll = tok >> 4
+            if ll == 15:
+                while True:
+                    c = src[i]
+                    i += 1
+                    ll += c
+                    if c != 255:
+                        break
+            if i + ll > n:
+                raise GdsError("LZ4: literals run past the end of the block")
+            out += src[i:i + ll]
+            i += ll
+            if i >= n:
+                break
+            off = src[i] | (src[i + 1] << 8)
+            i += 2
+            if off == 0:
+                raise GdsError("LZ4: zero offset")
+            ml = (tok & 15) + 4
+            if (tok & 15) == 15:
+                while True:
+                    c = src[i]
+                    i += 1
+                    ml += c
+                    if c != 255:
+                        break
+            st = len(out) - off
+            if st < 0:
+                raise GdsError("LZ4: offset before the start of the block")
+            if off >= ml:
+                out += out[st:st + ml]
+            else:
+                seg = bytes(out[st:])              # the last `off` bytes, repeated
+                reps = -(-ml // off)
+                out += (seg * reps)[:ml]
+    except IndexError:
+        raise GdsError("LZ4: block truncated inside a sequence") from None
     if raw_size is not None and len(out) != raw_size:
         raise GdsError("LZ4: block size mismatch")
     return bytes(out)

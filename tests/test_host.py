@@ -23,7 +23,7 @@ def test_abi_exports_every_declared_symbol():
     assert L.sgx_row_stride(430000) == 107520 and L.sgx_row_stride(1000) == 256
     # struct layouts agree with the header (sizes the C side computes)
     assert ctypes.sizeof(_lib.SgxModel) == 4 * 4 + 7 * 8 + 10 * 8
-    assert ctypes.sizeof(_lib.SgxStats) == 5 * 8 + 3 * 4 + 2 * 4 + 4         # ms_kernel took the tail padding
+    assert ctypes.sizeof(_lib.SgxStats) == 5 * 8 + 3 * 4 + 2 * 4 + 2 * 4 + 3 * 4     # + ms_kernel, ms_lists; three_plane, n_unlisted, n_guarded
 
 
 def test_init_rejects_bad_models_without_gpu():
