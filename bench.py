@@ -263,6 +263,7 @@ def main():
                     help="library streams per GPU: with 2 the SPA stage of one step runs under the score stage of the next")
     ap.add_argument("--file-variants", type=int, default=12000,
                     help="variants written to a GDS file and scanned from it with seqAssocGLMM_SPA (file -> table rate); 0 = skip")
+    ap.add_argument("--grm-markers", type=int, default=100_000, help="markers of the null-model operator's figures in `secondary.grm`; 0 = skip")
     ap.add_argument("--secondary", type=int, default=1,
                     help="1: after the main measurement (rank 0, one GPU) a few steps of K = 13, c2 and c4 into `secondary`")
     args = ap.parse_args()
@@ -577,6 +578,10 @@ def main():
             c2.close()
             del c2
             torch.cuda.empty_cache()
+        # BASELINE config [4]: the null-model fit's operator (implicit-GRM mat-vec + one PCG solve) at N = 430 000 x 100 000 markers
+        if args.grm_markers > 0:
+            from bench_grm import measure_grm
+            secondary["grm"] = measure_grm(n, args.grm_markers, 5, 200, args.seed)
 
     if rank == 0:
         line = {

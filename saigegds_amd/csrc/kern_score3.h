@@ -749,7 +749,7 @@ s3_reduce_kernel(S3Plan pl, int M, int NCW, int NAF, int NBF, int NCB, const int
 	*reinterpret_cast<s3_v4i *>(accbuf + (size_t)v * stride + b * 16 + (lane & 15)) = sum;      // (stride is a multiple of 16 ints)
 }
 
-// ---- epilogue: one thread per variant.  As score_mfma_epilogue, with the missing-sample sums from the T3 pass
+// ---- epilogue: one thread per variant: integer recombination of the limb sums, with the missing-sample sums from the T3 pass
 // and the constant column worth 4 per allele (the position scales want a multiple of 4).  Variants whose
 // missing genotypes are not listed go onto `ovf_list` (counters[23]) for the FP64 kernel.
 template <int K>

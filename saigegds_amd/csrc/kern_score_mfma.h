@@ -317,77 +317,6 @@ __device__ __forceinline__ HiLo mf_limbs(const int *a, int nl = MF_NLIMB)
 	return hl(hi, lo);
 }
 
-// one thread per variant: integer recombination, then the common epilogue
-template <int K>
-__global__ void __launch_bounds__(256)
-score_mfma_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf,
-	SpaRec *__restrict__ recs, int *__restrict__ counters, int btop, int *__restrict__ fb_series, int *__restrict__ fb_exact, double *__restrict__ out8,
-	uint8_t *__restrict__ valid)
-{
-	constexpr int P = 2 * K + 2, CW = P - 1;     // score columns c' (K), e (K), s, w; column CW carries G^2
-	const int j = blockIdx.x * blockDim.x + threadIdx.x;
-	if (j >= M) return;
-	const int *a0 = accbuf + (size_t)j * ep.acc_stride;   // group 0: value plane + bit-1 fragment
-	const int *am0 = a0 + ep.gncol[0];                     // group 0: value columns over missing samples
-	const int N = md.N;
-	const int n3 = am0[ep.col_ones];
-	const long long AC = (long long)a0[ep.col_ones] - 3ll * n3;
-	const int n2 = a0[ep.col_b1 + ep.climb[CW]] / 2 - n3;  // bit-1 plane (0/2) against the ones column
-	const int n1 = (int)(AC - 2ll * n2);
-	const VarHead h = make_head(md, (double)AC, N - n3);
-	double *o = out8 + (size_t)j * 8;
-	if (!h.pass) { nan_row(o); valid[j] = 0; return; }
-	const double imp = 2 * h.AF;
-	double acc[P];
-	HiLo Wm = hl(0, 0), T3m = hl(0, 0);
-#pragma unroll
-	for (int c = 0; c < P; c++) {
-		const int g = ep.cgrp[c], cc = ep.ccol[c], nl = ep.climb[c];
-		if (nl == 0) { acc[c] = 0; continue; }            // derived below
-		const int *a = a0 + ep.goff[g];
-		const HiLo V = mf_limbs(a + cc, nl);
-		const HiLo T3 = mf_limbs(a + ep.gncol[g] + cc, nl);
-		const HiLo W = hl_axpy(-3, T3, V);
-		const double t3d = hl_to_double(T3);
-		double s;
-		if (!h.minus) s = hl_to_double(W) + imp * t3d;
-		else s = hl_to_double(hl(2 * ep.ftot_hi[c] - W.hi, 2 * ep.ftot_lo[c] - W.lo)) - imp * t3d;
-		acc[c] = ldexp(s, -ep.escale[c]);
-		if (c == CW) { Wm = W; T3m = T3; }
-	}
-	{
-		const HiLo B2 = mf_limbs(a0 + ep.col_b1, ep.climb[CW]);   // = 2 (T2 + T3), the plane holds 0/2
-		const HiLo H2 = hl(B2.hi / 2 - T3m.hi, B2.lo / 2 - T3m.lo);   // every limb sum of that plane is even
-		const double t3d = hl_to_double(T3m);
-		double w;
-		if (!h.minus) {
-			w = hl_to_double(hl_axpy(2, H2, Wm)) + imp * imp * t3d;
-		} else {
-			const HiLo S1 = hl_axpy(-2, H2, Wm);
-			// 4 (Ftot - S1 - H2 - T3) + S1
-			const HiLo R = hl(ep.ftot_hi[CW] - S1.hi - H2.hi - T3m.hi, ep.ftot_lo[CW] - S1.lo - H2.lo - T3m.lo);
-			w = hl_to_double(hl_axpy(4, R, S1)) + (2 - imp) * (2 - imp) * t3d;
-		}
-		acc[CW] = ldexp(w, -ep.escale[CW]);
-	}
-	if (ep.derive_c) {
-#pragma unroll
-		for (int x = 0; x < K; x++) {
-			double cx = 0;
-#pragma unroll
-			for (int y = 0; y < K; y++) cx = fma(ep.XVXi[x * K + y], acc[K + y], cx);
-			acc[x] = cx;
-		}
-	}
-	double cbuf[KMAX], pn, Ssc, v2sc;
-	valid[j] = 1;
-	if (score_epilogue<(P - 2) / 2>(md, h, acc, o, cbuf, &pn, &Ssc, &v2sc)) {
-		spa_push<K>(md, recs, counters, btop, fb_series, fb_exact, j, h.minus, h.minus ? (2 * h.Num - h.AC) : h.AC,
-			h.minus ? (N - n2) : (n1 + n2 + n3), h.lut, pn, Ssc, v2sc, cbuf);     // m1: SPA stage, carrier sums
-	}
-	atomicAdd(&counters[1], 1);
-}
-
 #endif /* MF_KERNEL_ONLY */
 
 // Lane-map self-test of v_mfma_i32_16x16x64_i8 with asymmetric integer data:
