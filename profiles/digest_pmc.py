@@ -48,10 +48,12 @@ for k in sorted(set(rd) | set(wr)):
                "fetch_doubled": bool(wide)}
 score = [v for k, v in kern.items() if k.startswith("score3_kernel") or k.startswith("score_mfma_kernel")]
 spa = [v for k, v in kern.items() if k.startswith("spa")]
+lists = [v for k, v in kern.items() if k.startswith("s3_lists_t3_kernel") or k.startswith("s3_lists_kernel")]
 out = dict(meta)
 out["steps_profiled"] = steps
 out["score_hbm_bytes_per_launch"] = int(sum(v["read_bytes_per_step"] + v["write_bytes_per_step"] for v in score))
 out["spa_hbm_bytes_per_step"] = int(sum(v["read_bytes_per_step"] + v["write_bytes_per_step"] for v in spa))
+out["lists_hbm_bytes_per_launch"] = int(sum(v["read_bytes_per_step"] + v["write_bytes_per_step"] for v in lists))
 out["all_kernels_hbm_bytes_per_step"] = int(sum(v["read_bytes_per_step"] + v["write_bytes_per_step"] for v in kern.values()))
 out["kernels"] = kern
 json.dump(out, open(sys.argv[4], "w"), indent=1)

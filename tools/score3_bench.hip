@@ -20,7 +20,7 @@
 
 static uint64_t sm64(uint64_t &x) { x += 0x9E3779B97F4A7C15ull; uint64_t z = x; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); }
 
-__global__ void fill_codes(uint32_t *dst, size_t ndw, uint64_t seed)
+__global__ void fill_codes(uint32_t *dst, size_t ndw, uint64_t seed, uint32_t miss16 = 66)
 {
 	for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < ndw; i += (size_t)gridDim.x * blockDim.x) {
 		uint64_t x = seed + i * 0x9E3779B97F4A7C15ull;
@@ -28,7 +28,7 @@ __global__ void fill_codes(uint32_t *dst, size_t ndw, uint64_t seed)
 		for (int s = 0; s < 16; s++) {
 			x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
 			const uint32_t u = (uint32_t)(x >> 40) & 0xFFFF;       // 16-bit uniform
-			const uint32_t code = u < 66 ? 3u : (u < 50000 ? 0u : (u < 62000 ? 1u : 2u));
+			const uint32_t code = u < miss16 ? 3u : (u < 50000 ? 0u : (u < 62000 ? 1u : 2u));
 			w |= code << (2 * s);
 		}
 		dst[i] = w;
@@ -89,7 +89,7 @@ static float run(const char *name, const uint8_t *A, const uint8_t *Fl, int ntil
 
 // CPU check: sums of the item slabs per (variant, column) against the direct sum
 template <int NBF, int NAF, int WAVES, int NLA, int NLB, int DA, int DB, int NCB = 1, int NBUF = 2, int RM = 0, bool MISS = false>
-static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu, size_t row_pad = 0)
+static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu, size_t row_pad = 0, uint32_t miss16 = 300)
 {
 	const int ntile = 2 * ((N + 511) / 512);
 	const size_t nfrag = (M + 15) / 16, abytes = nfrag * (size_t)ntile * 1024;
@@ -103,7 +103,7 @@ static int check(const char *name, int N, size_t M, int wg_per_cu, int n_cu, siz
 	for (size_t v = 0; v < nfrag * 16; v++)
 		for (size_t s = 0; s < (size_t)ntile * 256; s++) {
 			const uint32_t u = (uint32_t)(sm64(x) & 0xFFFF);
-			code[v * ntile * 256 + s] = (v < M && s < (size_t)N) ? (u < 300 ? 3 : (u < 40000 ? 0 : (u < 56000 ? 1 : 2))) : (uint8_t)(sm64(x) & 3);   // padding holds garbage codes
+			code[v * ntile * 256 + s] = (v < M && s < (size_t)N) ? (u < miss16 ? 3 : (u < 40000 ? 0 : (u < 56000 ? 1 : 2))) : (uint8_t)(sm64(x) & 3);   // padding holds garbage codes
 		}
 	// padding samples (>= N) must see zero limbs, as sgx_init writes them
 	for (int t = 0; t < ntile; t++)
@@ -309,6 +309,9 @@ int main(int argc, char **argv)
 #define CHKM(NBF, NAF, NC, NLA, NLB, DA, DB) bad += check<NBF, NAF, NC, NLA, NLB, DA, DB, 1, 2, 1, true>("three-plane form", 1900 + 41 * NBF, 500 + NBF, 1, 8, (NBF & 1) * 64);
 		S3_FOR_EACH_NBF_MISS(CHKM)
 #undef CHKM
+		bad += check<4, 2, 8, 3, 1, 2, 2, 1, 2, 1, true>("three planes, 1 missing code in 65536", 5000, 700, 1, 8, 0, 1);
+		bad += check<4, 2, 8, 3, 1, 2, 2, 1, 2, 1, true>("three planes, no missing code", 3000, 300, 1, 8, 64, 0);
+		bad += check<4, 2, 8, 3, 1, 2, 2, 1, 2, 1, true>("three planes, 5 % missing", 3000, 300, 1, 8, 0, 3277);
 		return bad ? 1 : 0;
 	}
 	const int N = argc > 1 ? atoi(argv[1]) : 430000;
@@ -338,7 +341,7 @@ int main(int argc, char **argv)
 		const size_t bpv = (size_t)ntile * 64;
 		uint8_t *Ar;
 		CK(hipMalloc((void **)&Ar, M * bpv));
-		fill_codes<<<4096, 256>>>((uint32_t *)Ar, M * bpv / 4, 12345);
+		fill_codes<<<4096, 256>>>((uint32_t *)Ar, M * bpv / 4, 12345, getenv("MISS16") ? (uint32_t)atoi(getenv("MISS16")) : 66u);
 		CK(hipDeviceSynchronize());
 		{
 			// small shapes against a CPU walk (N not a multiple of 64, a long-range shape), then the timing
