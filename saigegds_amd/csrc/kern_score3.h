@@ -207,20 +207,19 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 			};
 #pragma unroll
 			for (int d = 0; d < DA; d++) if (pa.k < nk) { issue(); ahead++; }
-			int k = 0;                                            // tiles of this workgroup's stream so far
+			// a pair per iteration, its two barriers written out (every item is whole pairs): the wait belongs to the first.
+			// (With one barrier in the loop and the wait under `if (even tile)` the compiler issued s_waitcnt vmcnt(0) in front
+			// of EVERY barrier: the pair fetched behind an even barrier then had one tile step to land, not two.)
 			while (pc.k < nk) {
-				if (!(k & 1)) {
-					// the pair this barrier opens has landed; `ahead - 1` younger pairs may fly
-					if (ahead == DA && DA > 1) { if (l < NHI) S3_WAITCNT_VM(2 * (PLO + 1) * (DA - 1)); else S3_WAITCNT_VM(2 * PLO * (DA - 1)); }
-					else S3_WAITCNT_VM(0);
-				}
+				// the pair this barrier opens has landed; `ahead - 1` younger pairs may fly
+				if (ahead == DA && DA > 1) { if (l < NHI) S3_WAITCNT_VM(2 * (PLO + 1) * (DA - 1)); else S3_WAITCNT_VM(2 * PLO * (DA - 1)); }
+				else S3_WAITCNT_VM(0);
 				__builtin_amdgcn_s_barrier();
-				if (!(k & 1)) {
-					// the consumers have left the pair before this one: its slot takes the pair DA ahead
-					ahead--;
-					if (pa.k < nk) { issue(); ahead++; }
-				}
-				k++;
+				// the consumers have left the pair before this one: its slot takes the pair DA ahead
+				ahead--;
+				if (pa.k < nk) { issue(); ahead++; }
+				pos_next(pc);
+				__builtin_amdgcn_s_barrier();                     // the pair's second tile: nothing to wait for, nothing to issue
 				pos_next(pc);
 			}
 		} else if (rows) {
