@@ -552,6 +552,25 @@ def test_fixed_point_guard():
         assert_table_close(out, valid, ref, ref_valid, what="guard off")
 
 
+def test_rows_longer_than_the_list_kernels_registers():
+    """N > 524 288: a sample range of the list kernels (one sixteenth of a row) no longer fits the eight 16-byte
+    pieces a lane holds in registers, so they walk it twice / in strides (kern_lists.h, the `long ranges` branches),
+    in the row-major call and in a block load; both tables against the oracle, 0.3 % missing."""
+    from saigegds_amd._lib import Block
+    n, m = 540_001, 40
+    sm, packed = _synthetic_case(n, m, "binary", 0.02, seed=67, miss=3e-3, lo=-2.0)
+    ref, ref_valid = _oracle(sm).scan_2bit(packed)
+    assert ref_valid.sum() >= 30
+    with _scanner(sm) as sc, Block(n, m) as blk:
+        sc.set_option("three_plane", 0)
+        out, valid = sc.scan_2bit(packed)
+        assert_table_close(out, valid, ref, ref_valid, what="long rows, row-major call")
+        sc.load_block(blk, packed)
+        o2, v2 = _scan_block(sc, blk, m)
+        assert sc.stats()["three_plane"] == 0 and sc.stats()["n_unlisted"] == 0
+        assert_table_close(o2, v2, ref, ref_valid, what="long rows, resident block")
+
+
 def test_two_lanes_give_identical_tables():
     """"lanes" = 2 .. 4: successive device-resident scans go round-robin over that many streams with their own
     workspace; every block's table must equal the single-lane one, and the totals must add up."""

@@ -30,6 +30,6 @@ find $OUT/prof2 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_two_lane
 find $OUT/prof1 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_one_lane.csv \;
 find $OUT/prof13 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_k13_one_lane.csv \;
 find $OUT/prof1 -name "*kernel_trace.csv" -exec python3 profiles/show_timeline.py {} \; > $OUT/timeline_one_lane.txt || true
-find $OUT/prof2 -name "*kernel_trace.csv" -exec python3 profiles/show_timeline.py {} 4 \; > $OUT/timeline_two_lanes.txt || true
+find $OUT/prof2 -name "*kernel_trace.csv" -exec python3 profiles/show_timeline.py {} 13 3 \; > $OUT/timeline_two_lanes.txt || true
 rm -rf $OUT/prof1 $OUT/prof2 $OUT/prof13 $OUT/pmc_rd $OUT/pmc_wr $OUT/pmc_sq
 ls -la $OUT
