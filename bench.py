@@ -383,10 +383,11 @@ def main():
             "score_stage_ms": round(r["iso"][0], 4), "spa_stage_ms": round(r["iso"][1], 4), "lists_ms": round(r["iso"][3], 4),
             "note": "one lane (no SPA stage of the previous step running beside it), medians of 9 steps outside the timed region"},
         "stages": {
-            "lists": {"avg_ms": round(ms_lists, 4), "kernel": "s3_lists_kernel", "algorithmic_bytes": block * row_bytes,
+            "lists": {"avg_ms": round(ms_lists, 4), "kernel": "s3_lists_t3_kernel", "algorithmic_bytes": block * row_bytes,
                       "frac_of_hbm_peak": round(block * row_bytes / (max(ms_lists, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": "hbm",
-                      "note": "one read of the rows: positions of the missing genotypes for the sparse pass (the rows are read "
-                              "twice per step: here and by score3_kernel)"},
+                      "note": "one read of the rows: finds the missing genotypes and gathers their score vectors on the spot (the sparse "
+                              "pass of the two-plane form; 0 where a step took the three-plane form); the rows are read twice per "
+                              "step: here and by score3_kernel"},
             "score": {"avg_ms": round(ms_score, 4), "launches_per_step": int(tot["score_launches"] // steps),
                       "algorithmic_bytes": alg_bytes, "hbm_bytes": traffic, "bound": BOUND_NAME[binding],
                       "frac_of_hbm_peak": round(alg_bytes / (ms_score * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},

@@ -174,7 +174,7 @@ int sgx_scan_2bit_dev(sgx_handle *h, const uint8_t *packed_dev,
  * (non-zero codes, or the codes other than 2 where the alt allele is the major one).  One loaded block
  * can be scanned with any number of models (phenotypes): each scan then streams the rows once.
  *   sgx_block_create    device storage for up to max_variants rows of n_samp samples
- *   sgx_block_bytes     what that takes (about 1.1 x the packed rows at large N)
+ *   sgx_block_bytes     what that takes (about 1.2 x the packed rows at large N)
  *   sgx_block_load_dev  rows already in this GPU's memory (bytes_per_variant a multiple of 16,
  *                       >= sgx_row_stride(n_samp), 16-byte aligned); asynchronous on the handle's stream;
  *                       a load waits for the scans that still read the block
