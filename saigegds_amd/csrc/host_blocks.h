@@ -105,7 +105,7 @@ static S3Lists block_lists(const sgx_block *b)
 	S3Lists L{};
 	L.idx = b->idx; L.idx_cap = (unsigned)b->idx_cap; L.cursor = b->cursor; L.lstart = b->lstart; L.lcnt = b->lcnt;
 	L.nzp = b->nzp; L.n2p = b->n2p; L.ld = b->cap; L.nr = b->nr;
-	L.nsub = (int)std::max<size_t>(1, std::min<size_t>(S3_NSUB, (b->cap * (size_t)b->nr + 3) / 4));
+	s3_lists_setup(L, b->ntile, (b->cap * (size_t)b->nr + 3) / 4);
 	return L;
 }
 static RowsRef block_rows(const sgx_block *b)
@@ -119,13 +119,13 @@ static RowsRef block_rows(const sgx_block *b)
 // block_finish once
 static int block_put_rows(sgx_block *b, const uint8_t *rows_dev, size_t bpv, size_t v_first, size_t m, hipStream_t st)
 {
-	const unsigned grid = (unsigned)(((m + 3) / 4) * (size_t)b->nr);
+	const dim3 grid((unsigned)((m + 3) / 4), (unsigned)b->nr);
 	const S3Lists L = block_lists(b);
 	if (b->lists_only)
-		hipLaunchKernelGGL((s3_lists_kernel<8, false, false>), dim3(grid), dim3(256), 0, st, rows_dev, bpv, b->N, (int)m, (int)v_first, b->ntile, L,
+		hipLaunchKernelGGL((s3_lists_kernel<8, false, false>), grid, dim3(256), 0, st, rows_dev, bpv, b->N, (int)m, (int)v_first, b->ntile, L,
 			(uint8_t *)nullptr, (size_t)0);
 	else
-		hipLaunchKernelGGL((s3_lists_kernel<8, true, true>), dim3(grid), dim3(256), 0, st, rows_dev, bpv, b->N, (int)m, (int)v_first, b->ntile, L,
+		hipLaunchKernelGGL((s3_lists_kernel<8, true, true>), grid, dim3(256), 0, st, rows_dev, bpv, b->N, (int)m, (int)v_first, b->ntile, L,
 			b->rows, b->bpv);
 	HIPCHK(hipGetLastError());
 	return SGX_OK;

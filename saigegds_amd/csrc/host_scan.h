@@ -37,7 +37,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	h->used_miss = miss;
 	HIPCHK(hipStreamWaitEvent(st, b->ready, 0));
 	HIPCHK(hipEventRecord(h->ev[0], st));            // (counters and queue cursors: zeroed by s3_reduce_kernel)
-	int rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)(b->nr + 1) * M * md.P * 2);      // per-range partials, then the totals
+	int rc = ensure_buf(h, &h->s3_t3, &h->s3_t3_cap, (size_t)b->nr * M * md.P * 2);            // per-range sums over the missing samples (the epilogue adds them up)
 	if (rc) return rc;
 	rc = ensure_buf(h, &h->s3_ovf, &h->s3_ovf_cap, M);
 	if (rc) return rc;
@@ -75,11 +75,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	//  * launched together onto an idle GPU the pass's 25 000 small workgroups and the kernel's 256 persistent ones
 	//    fight for the CUs (kernel traces: 1.9 ms for the kernel and 1.1 ms for the pass in those steps).
 	// (round 3, tools/README.md: the three orders measured)
-	if (t3_done) {
-		const size_t n3e = M * (size_t)md.P * 2;
-		hipLaunchKernelGGL(s3_t3_sum_kernel, dim3((unsigned)((n3e + 255) / 256)), dim3(256), 0, st, n3e, b->nr, h->s3_t3, h->s3_t3 + (size_t)b->nr * n3e);
-		HIPCHK(hipGetLastError());
-	} else {
+	if (!t3_done) {
 	HIPCHK(hipEventRecord(h->s3_fork, st));                  // (the side stream starts where this stream stands NOW)
 	HIPCHK(hipStreamWaitEvent(h->s3_side, h->s3_fork, 0));
 	{
@@ -92,8 +88,6 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 		else if (PP == 16) hipLaunchKernelGGL(s3_t3_kernel<16>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, L, h->s3_t3);
 		else if (PP == 32) hipLaunchKernelGGL(s3_t3_kernel<32>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, L, h->s3_t3);
 		else hipLaunchKernelGGL(s3_t3_kernel<64>, g3, dim3(256), 0, s2, (int)M, md.P, h->dQ, L, h->s3_t3);
-		const size_t n3e = M * (size_t)md.P * 2;
-		hipLaunchKernelGGL(s3_t3_sum_kernel, dim3((unsigned)((n3e + 255) / 256)), dim3(256), 0, s2, n3e, b->nr, h->s3_t3, h->s3_t3 + (size_t)b->nr * n3e);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(h->s3_join, s2));
 	}
@@ -133,8 +127,8 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	const int btop = md.quant ? 0 : (int)(2 * M);
 	switch (md.K) {
 #define ECASE(KK) case KK:                                                                     \
-	hipLaunchKernelGGL((score3_epilogue<KK>), dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (int)M, md, ep, h->mf_acc, acc_stride, \
-		miss ? 16 * NBF : 0, h->s3_t3 + (size_t)b->nr * M * md.P * 2, b->n3, b->ovf, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid, h->guard_tol); \
+	hipLaunchKernelGGL((score3_epilogue<KK>), dim3((unsigned)((M + s3e_vb(KK) - 1) / s3e_vb(KK))), dim3(s3e_vb(KK)), 0, st, (int)M, md, ep, h->mf_acc, acc_stride, \
+		miss ? 16 * NBF : 0, h->s3_t3, b->nr, L.lcnt, L.ld, h->s3_ovf, h->recs, h->counters, btop, h->fb_spa2, h->fb_x2, out8, valid, h->guard_tol, (h->owner ? h->owner : h)->spa_abl >> 16); \
 	hipLaunchKernelGGL((score2b_kernel<2 * KK + 2, 256>), dim3((unsigned)std::min<size_t>(M, 4 * (size_t)h->n_cu)), dim3(256), 0, st, \
 		rr, (int)M, md, h->recs, h->counters, out8, valid, (const int *)h->s3_ovf, 23, btop, h->fb_spa2, h->fb_x2); \
 	break;
@@ -144,7 +138,7 @@ static int launch_block_scan(sgx_handle *h, const sgx_block *b, size_t M, double
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(h->ev[1], st));
-	h->stats.score_launches = 6;
+	h->stats.score_launches = 5;
 	st = h->stream;                                  // the SPA stage: low priority, behind the score chain
 	HIPCHK(hipStreamWaitEvent(st, h->ev[1], 0));
 	rc = launch_spa<IN_2BIT>(h, rr, M, out8, lazy_dense);
@@ -266,14 +260,14 @@ static int scan_rows_dev(sgx_handle *lane, int which, const uint8_t *rows_dev, s
 	tb->ext_rows = rows_dev; tb->ext_bpv = bpv;
 	if (rows_take_three_planes(lane)) return launch_block_scan(lane, tb, M, out8, valid, lazy_dense, true);
 	// one pass over the rows: the missing genotypes of every (range, variant), their sums of Q gathered on the spot
-	rc = ensure_buf(lane, &lane->s3_t3, &lane->s3_t3_cap, (size_t)(tb->nr + 1) * M * lane->md.P * 2);
+	rc = ensure_buf(lane, &lane->s3_t3, &lane->s3_t3_cap, (size_t)tb->nr * M * lane->md.P * 2);
 	if (rc) return rc;
 	HIPCHK(hipEventRecord(lane->ev_lists, lane->hstream));
 	lane->lists_timed = true;
 	{
 		const S3Lists L = block_lists(tb);
 		const int P = lane->md.P, PP = P <= 8 ? 8 : P <= 16 ? 16 : P <= 32 ? 32 : 64;
-		const dim3 grid((unsigned)(((M + 3) / 4) * (size_t)tb->nr));
+		const dim3 grid((unsigned)((M + 3) / 4), (unsigned)tb->nr);
 		hipStream_t st = lane->hstream;
 		if (PP == 8) hipLaunchKernelGGL((s3_lists_t3_kernel<8, 8>), grid, dim3(256), 0, st, rows_dev, bpv, tb->N, (int)M, tb->ntile, L, P, lane->dQ, lane->s3_t3);
 		else if (PP == 16) hipLaunchKernelGGL((s3_lists_t3_kernel<8, 16>), grid, dim3(256), 0, st, rows_dev, bpv, tb->N, (int)M, tb->ntile, L, P, lane->dQ, lane->s3_t3);
@@ -281,8 +275,7 @@ static int scan_rows_dev(sgx_handle *lane, int which, const uint8_t *rows_dev, s
 		else hipLaunchKernelGGL((s3_lists_t3_kernel<8, 64>), grid, dim3(256), 0, st, rows_dev, bpv, tb->N, (int)M, tb->ntile, L, P, lane->dQ, lane->s3_t3);
 		HIPCHK(hipGetLastError());
 	}
-	rc = block_finish(tb, M, lane->hstream);
-	if (rc) return rc;
+	// (no kernel between this pass and the contraction: the epilogue adds up the ranges' sums and counts itself)
 	return launch_block_scan(lane, tb, M, out8, valid, lazy_dense, false, true);
 }
 

@@ -21,6 +21,22 @@ __device__ __forceinline__ int lst_scan_incl(int v)
 	return v;
 }
 
+// a 16-byte piece of a row, read once: the streaming hint keeps the rows from pushing the table Q (which the same
+// kernel gathers from, a few MB per sample range) out of the L2
+__device__ __forceinline__ uint4 lst_load_stream(const void *p)
+{
+	typedef uint32_t lst_u4 __attribute__((ext_vector_type(4)));
+	const lst_u4 v = __builtin_nontemporal_load(reinterpret_cast<const lst_u4 *>(p));
+	return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+__device__ __forceinline__ void lst_store_stream(void *p, const uint4 &w)
+{
+	typedef uint32_t lst_u4 __attribute__((ext_vector_type(4)));
+	lst_u4 v; v.x = w.x; v.y = w.y; v.z = w.z; v.w = w.w;
+	__builtin_nontemporal_store(v, reinterpret_cast<lst_u4 *>(p));
+}
+
 __device__ __forceinline__ uint32_t lst_keep(int keep)
 {
 	return (keep >= 16) ? 0xFFFFFFFFu : ((keep <= 0) ? 0u : ((1u << (2 * keep)) - 1u));
@@ -47,8 +63,19 @@ struct S3Lists {
 	int *nzp, *n2p;        // may be null
 	size_t ld;             // leading dimension of the [nr][ld] arrays (>= the block's variants)
 	int nr;                // sample ranges = s3_nranges(ntile)
-	int nsub;              // sub-pools in use: min(S3_NSUB, workgroups of a full load), so that small blocks keep large sub-pools
+	int nsub;              // sub-pools in use: a power of two <= min(S3_NSUB, workgroups of a full load), so that small blocks keep large sub-pools
+	unsigned subcap;       // idx_cap / nsub
+	int rt[S3_NR + 1];     // rt[g] = s3_range_t0(g, ntile, nr): the kernels below are short, a 64-bit division per wave showed in their time
 };
+// the host's part of the struct: ranges and sub-pools (idx_cap, nr set; full_wg = workgroups of a full load)
+static inline void s3_lists_setup(S3Lists &L, int ntile, size_t full_wg)
+{
+	for (int g = 0; g <= S3_NR; g++) L.rt[g] = s3_range_t0(g < L.nr ? g : L.nr, ntile, L.nr);
+	int ns = 1;
+	while (ns * 2 <= S3_NSUB && (size_t)ns * 2 <= full_wg) ns *= 2;
+	L.nsub = ns;
+	L.subcap = L.idx_cap / (unsigned)ns;
+}
 
 // One wave per (variant v, sample range g), four variants of a range per workgroup: the range's 16-byte pieces (64 samples) are read with all lanes'
 // loads in flight at once (MAXLD uint4 per lane: 8 KiB per wave; a range of N = 430 000 is 6.6 KiB), the
@@ -69,16 +96,17 @@ s3_lists_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, int 
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 	// workgroup = (range g, four consecutive variants): its four segments are reserved by ONE atomic add and lie
 	// behind each other, so that a wave of the T3 pass (eight consecutive variants of a range) reads two runs
-	const int nq = (m + 3) / 4, g = (int)(blockIdx.x / nq), vl = (int)(blockIdx.x % nq) * 4 + wid, v = v_first + vl;
+	// grid = (groups of four variants, ranges)
+	const int g = (int)blockIdx.y, vl = (int)blockIdx.x * 4 + wid, v = v_first + vl;
 	const bool live = vl < m;
-	const int t0 = s3_range_t0(g, ntile, L.nr), t1 = s3_range_t0(g + 1, ntile, L.nr);
+	const int t0 = L.rt[g], t1 = L.rt[g + 1];
 	const int npiece = live ? (t1 - t0) * 4 : 0, p0 = t0 * 4;   // pieces of the range; first piece of the row
 	const uint8_t *src = rows + (size_t)(live ? vl : 0) * bpv + (size_t)t0 * 64;
 	uint8_t *out = COPY ? dst + (size_t)(live ? v : 0) * dst_bpv + (size_t)t0 * 64 : nullptr;
 	const size_t e = (size_t)g * L.ld + v;
 	__shared__ int sh_tot[4];
 	__shared__ unsigned sh_base;
-	const unsigned sub = blockIdx.x % (unsigned)L.nsub, subcap = L.idx_cap / (unsigned)L.nsub;
+	const unsigned sub = (blockIdx.y * gridDim.x + blockIdx.x) & (unsigned)(L.nsub - 1), subcap = L.subcap;
 	const bool tail = (p0 + npiece) * 64 > N;                   // (wave-uniform) the range reaches past the last sample
 	// the piece with the samples >= N cleared
 	auto clip = [&](uint4 wv, int p) -> uint4 {
@@ -141,8 +169,8 @@ s3_lists_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, int 
 		for (int k = 0; k < MAXLD; k++) {
 			const int p = k * 64 + lane;
 			uint4 wv = make_uint4(0u, 0u, 0u, 0u);
-			if (p < npiece) wv = *reinterpret_cast<const uint4 *>(src + (size_t)p * 16);
-			if (COPY) { if (p < npiece) *reinterpret_cast<uint4 *>(out + (size_t)p * 16) = wv; }
+			if (p < npiece) wv = lst_load_stream(src + (size_t)p * 16);
+			if (COPY) { if (p < npiece) lst_store_stream(out + (size_t)p * 16, wv); }
 			wv = clip(wv, p);
 			mk[k] = miss64(wv);
 			c += __popcll(mk[k]);
@@ -193,6 +221,11 @@ s3_lists_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, int 
 // lcnt[g][v] = the count, or -1 when the segment holds more than S3_LT_CAP entries (the variant then takes the
 // FP64 kernel; a block with that many missing genotypes is the three-plane form's business).
 #define S3_LT_CAP 256
+// Measured on the way (tools/README.md, round 4): the wave's prologue held two 64-bit divisions (the range's first
+// tile, the workgroup's place in a 1-D grid) -- now grid = (four variants, range) and the ranges' first tiles come from
+// the host; the rows are read with the streaming hint (lst_load_stream), or they push Q out of the L2 and 40 % of the
+// gathers go to memory (1.08 -> 0.91 ms per 5.4 GB at N = 430 000); a form with a third fewer vector instructions
+// (detect pieces with a missing code first, compact them, read them again) was slower, its second read missing the L2.
 template <int MAXLD, int PP>
 __global__ void __launch_bounds__(256)
 s3_lists_t3_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, int ntile, S3Lists L,
@@ -201,9 +234,9 @@ s3_lists_t3_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, i
 	constexpr int TPE = 64 / PP;
 	__shared__ unsigned ent[4][S3_LT_CAP];
 	const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-	const int nq = (m + 3) / 4, g = (int)(blockIdx.x / nq), v = (int)(blockIdx.x % nq) * 4 + wid;
+	const int g = (int)blockIdx.y, v = (int)blockIdx.x * 4 + wid;
 	if (v >= m) return;                                        // (no workgroup barrier below)
-	const int t0 = s3_range_t0(g, ntile, L.nr), t1 = s3_range_t0(g + 1, ntile, L.nr);
+	const int t0 = L.rt[g], t1 = L.rt[g + 1];
 	const int npiece = (t1 - t0) * 4, p0 = t0 * 4;
 	const uint8_t *src = rows + (size_t)v * bpv + (size_t)t0 * 64;
 	const size_t e = (size_t)g * L.ld + v;
@@ -235,7 +268,7 @@ s3_lists_t3_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, i
 		for (int k = 0; k < MAXLD; k++) {
 			const int p = k * 64 + lane;
 			uint4 wv = make_uint4(0u, 0u, 0u, 0u);
-			if (p < npiece) wv = *reinterpret_cast<const uint4 *>(src + (size_t)p * 16);
+			if (p < npiece) wv = lst_load_stream(src + (size_t)p * 16);
 			mk[k] = miss64(clip(wv, p));
 			c += __popcll(mk[k]);
 		}
@@ -248,7 +281,7 @@ s3_lists_t3_kernel(const uint8_t *__restrict__ rows, size_t bpv, int N, int m, i
 		for (int pb = 0; pb < npiece; pb += 64) {             // (wave-uniform bounds)
 			const int p = pb + lane;
 			uint4 wv = make_uint4(0u, 0u, 0u, 0u);
-			if (p < npiece) wv = *reinterpret_cast<const uint4 *>(src + (size_t)p * 16);
+			if (p < npiece) wv = lst_load_stream(src + (size_t)p * 16);
 			const unsigned long long mm = miss64(clip(wv, p));
 			const int c = __popcll(mm), incl = lst_scan_incl(c);
 			emit(mm, p, tot + incl - c);

@@ -748,74 +748,168 @@ s3_reduce_kernel(S3Plan pl, int M, int NCW, int NAF, int NBF, int NCB, const int
 	*reinterpret_cast<s3_v4i *>(accbuf + (size_t)v * stride + b * 16 + (lane & 15)) = sum;      // (stride is a multiple of 16 ints)
 }
 
-// ---- epilogue: one thread per variant: integer recombination of the limb sums, with the missing-sample sums from the T3 pass
-// and the constant column worth 4 per allele (the position scales want a multiple of 4).  Variants whose
-// missing genotypes are not listed go onto `ovf_list` (counters[23]) for the FP64 kernel.
+// ---- epilogue: the limb sums of a variant -> its row of the table (or its place in the SPA stage's lists).
+// A workgroup takes s3e_vb(K) variants in three steps:
+//  0. a thread per variant (as many threads as variants): missing genotypes (the per-range counts of the list pass / the block, or the missing plane's
+//     constant column), allele counts, filters (make_head).  Variants whose missing genotypes are not listed go onto
+//     `ovf_list` (counters[23]) for the FP64 kernel.
+//  1. a thread per (variant, score column): integer recombination of the column's limb sums with the sums over the missing
+//     samples -- the per-range partials of the sparse pass are added here (no kernel of their own), or the missing plane's
+//     limbs -- and the constant column worth 4 per allele (the position scales want a multiple of 4).  Consecutive lanes
+//     read consecutive addresses, every load of a thread is in flight before the first is used.  (One thread per variant
+//     doing the columns one after the other waited for each of its 50 - 460 loads in turn: 60 us at K = 3, 0.65 ms at K = 13.)
+//  2. a thread per variant again: the guard on the fixed-point columns, the score test, the SPA stage's record.
+// (The per-variant steps keep every wave of the workgroup busy: with 64 variants per 256 threads step 2 ran on the first
+// wave of every workgroup only -- on one SIMD of each CU -- and took 0.59 ms instead of 0.03.)
+__host__ __device__ constexpr int s3e_vb(int K) { return K <= 8 ? 256 : 128; }      // variants = threads per workgroup
 template <int K>
 __global__ void __launch_bounds__(256)
 score3_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf, int acc_stride, int miss_off,
-	const long long *__restrict__ t3part /* [M][P][2] totals */,
-	const int *__restrict__ n3buf, const uint8_t *__restrict__ ovf, int *__restrict__ ovf_list,
+	const long long *__restrict__ t3part /* [nr][M][P][2] per-range sums over the missing samples */, int nr,
+	const int *__restrict__ lcnt /* [nr][ld] listed missing genotypes per range, -1: not listed */, size_t ld, int *__restrict__ ovf_list,
 	SpaRec *__restrict__ recs, int *__restrict__ counters, int btop, int *__restrict__ fb_series, int *__restrict__ fb_exact,
-	double *__restrict__ out8, uint8_t *__restrict__ valid, double guard_tol)
+	double *__restrict__ out8, uint8_t *__restrict__ valid, double guard_tol, int dbg = 0)
 {
 	constexpr int P = 2 * K + 2, CW = P - 1;     // score columns c' (K), e (K), s, w; column CW carries G^2
-	const int j = blockIdx.x * blockDim.x + threadIdx.x;
-	// miss_off = 0: the sums over the missing samples come from the sparse pass (t3part, n3buf; variants it could not
-	// list go to the FP64 kernel); miss_off > 0: the three-plane form, the missing plane's limb sums sit at that
-	// offset of the variant's row (and its constant column counts the missing genotypes)
-	const int *a0 = accbuf + (size_t)min(j, M - 1) * acc_stride;
-	const int n3 = j < M ? (miss_off ? a0[miss_off + ep.col_ones] / 4 : n3buf[j]) : 0;
-	{
-		// census of the step's missing genotypes (units of 64) for the host's choice between the two forms
-		const int tot = wave_total_i(n3);
-		if ((threadIdx.x & 63) == 0 && tot >= 64) atomicAdd(&counters[22], tot >> 6);
-	}
-	if (j >= M) return;
-	if (!miss_off && ovf[j]) { ovf_list[atomicAdd(&counters[23], 1)] = j; return; }
+	constexpr int S3E_VB = s3e_vb(K);
+	__shared__ double s_acc[S3E_VB][P | 1];
+	__shared__ double s_imp[S3E_VB];
+	__shared__ int s_n[S3E_VB][4];                // n1, n2, n3, state (0: done with, 1: minor allele alt, 2: flipped)
+	__shared__ long long s_ftot[P][2];
+	__shared__ int s_col[P][3];                   // first limb column, limbs, scale exponent
+	const int tid = threadIdx.x, j0 = blockIdx.x * S3E_VB;
 	const int N = md.N;
-	const long long AC = (long long)(a0[ep.col_ones] / 4) - 3ll * n3;
-	const int n2 = a0[ep.col_b1 + ep.climb[CW]] / 8 - n3;  // bit-1 plane (0/2) against the constant column (4)
-	const int n1 = (int)(AC - 2ll * n2);
-	const VarHead h = make_head(md, (double)AC, N - n3);
-	double *o = out8 + (size_t)j * 8;
-	if (!h.pass) { nan_row(o); valid[j] = 0; return; }
-	const double imp = 2 * h.AF;
-	auto t3_of = [&](int c) -> HiLo {
-		if (miss_off) return mf_limbs(a0 + miss_off + ep.ccol[c], ep.climb[c]);
-		const long long *p = t3part + ((size_t)j * P + c) * 2;
-		return hl(p[0], p[1]);
-	};
-	double acc[P];
-	HiLo Wm = hl(0, 0), T3m = hl(0, 0);
+	if (dbg & 1) {
+		if (tid == 0)
 #pragma unroll
-	for (int c = 0; c < P; c++) {
-		const int cc = ep.ccol[c], nl = ep.climb[c];
-		if (nl == 0) { acc[c] = 0; continue; }            // derived below
-		const HiLo V = mf_limbs(a0 + cc, nl);
-		const HiLo T3 = t3_of(c);
+			for (int c = 0; c < P; c++) {
+				s_col[c][0] = ep.ccol[c]; s_col[c][1] = ep.climb[c]; s_col[c][2] = ep.escale[c];
+				s_ftot[c][0] = ep.ftot_hi[c]; s_ftot[c][1] = ep.ftot_lo[c];
+			}
+	} else
+	for (int c = tid; c < P; c += S3E_VB) {
+		s_col[c][0] = ep.ccol[c]; s_col[c][1] = ep.climb[c]; s_col[c][2] = ep.escale[c];
+		s_ftot[c][0] = ep.ftot_hi[c]; s_ftot[c][1] = ep.ftot_lo[c];
+	}
+	// ---- 0. per variant
+	{
+		const int j = j0 + tid;
+		const int *a0 = accbuf + (size_t)min(j, M - 1) * acc_stride;
+		int n3 = 0;
+		bool over = false;
+		if (miss_off) n3 = a0[miss_off + ep.col_ones] / 4;
+		else {
+			for (int g0 = 0; g0 < nr; g0 += 8) {
+				int cn[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++) cn[u] = lcnt[(size_t)min(g0 + u, nr - 1) * ld + min(j, M - 1)];
+#pragma unroll
+				for (int u = 0; u < 8; u++) if (g0 + u < nr) { over |= cn[u] < 0; n3 += cn[u] < 0 ? 0 : cn[u]; }
+			}
+		}
+		if (j >= M) n3 = 0;
+		{
+			// census of the step's missing genotypes (units of 64) for the host's choice between the two forms
+			const int tot = wave_total_i(n3);
+			if ((tid & 63) == 0 && tot >= 64) atomicAdd(&counters[22], tot >> 6);
+		}
+		int state = 0, n1 = 0, n2 = 0;
+		double imp = 0;
+		if (dbg & 8) over = false;
+		if (j < M) {
+			if (over) ovf_list[atomicAdd(&counters[23], 1)] = j;
+			else {
+				const long long AC = (long long)(a0[ep.col_ones] / 4) - 3ll * n3;
+				n2 = a0[ep.col_b1 + ep.climb[CW]] / 8 - n3;    // bit-1 plane (0/2) against the constant column (4)
+				n1 = (int)(AC - 2ll * n2);
+				const VarHead h = make_head(md, (double)AC, N - n3);
+				if (!h.pass) { nan_row(out8 + (size_t)j * 8); valid[j] = 0; }
+				else { state = h.minus ? 2 : 1; imp = 2 * h.AF; }
+			}
+		}
+		s_n[tid][0] = n1; s_n[tid][1] = n2; s_n[tid][2] = n3; s_n[tid][3] = state;
+		s_imp[tid] = imp;
+	}
+	__syncthreads();
+	// ---- 1. per (variant, column)
+	for (int task = tid; task < S3E_VB * P; task += S3E_VB) {
+		const int vl = task / P, c = task - vl * P, j = j0 + vl;
+		const int state = s_n[vl][3];
+		if (!state) continue;
+		const int cc = s_col[c][0], nl = s_col[c][1];
+		if (nl == 0) { s_acc[vl][c] = 0; continue; }           // derived below
+		const int *a0 = accbuf + (size_t)j * acc_stride;
+		const bool minus = state == 2;
+		const double imp = s_imp[vl];
+		// every load first: the column's limbs (those beyond nl read the last one again), the missing samples' sums
+		int lv[MF_NLIMB], lm[MF_NLIMB], lb[MF_NLIMB];
+#pragma unroll
+		for (int l = 0; l < MF_NLIMB; l++) lv[l] = a0[cc + min(l, nl - 1)];
+		HiLo T3 = hl(0, 0);
+		if (miss_off) {
+#pragma unroll
+			for (int l = 0; l < MF_NLIMB; l++) lm[l] = a0[miss_off + cc + min(l, nl - 1)];
+		} else if (!(dbg & 2)) {
+			const long long *p = t3part + ((size_t)j * P + c) * 2;
+			const size_t gs = (size_t)M * P * 2;
+			for (int g0 = 0; g0 < nr; g0 += 8) {
+				long long ph[8], pl[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++) { const long long *q = p + (size_t)min(g0 + u, nr - 1) * gs; ph[u] = q[0]; pl[u] = q[1]; }
+#pragma unroll
+				for (int u = 0; u < 8; u++) if (g0 + u < nr) { T3.hi += ph[u]; T3.lo += pl[u]; }
+			}
+		}
+		if (c == CW) {
+#pragma unroll
+			for (int l = 0; l < MF_NLIMB; l++) lb[l] = a0[ep.col_b1 + min(l, nl - 1)];
+		}
+		auto limbs = [&](const int (&x)[MF_NLIMB]) -> HiLo {
+			long long lo = 0, hi = 0;
+#pragma unroll
+			for (int l = 3; l >= 0; l--) lo = lo * 256 + (l < nl ? x[l] : 0);
+#pragma unroll
+			for (int l = MF_NLIMB - 1; l >= 4; l--) hi = hi * 256 + (l < nl ? x[l] : 0);
+			return hl(hi, lo);
+		};
+		const HiLo V = limbs(lv);
+		if (miss_off) T3 = limbs(lm);
 		const HiLo W = hl_axpy(-3, T3, V);
 		const double t3d = hl_to_double(T3);
-		double s;
-		if (!h.minus) s = hl_to_double(W) + imp * t3d;
-		else s = hl_to_double(hl(2 * ep.ftot_hi[c] - W.hi, 2 * ep.ftot_lo[c] - W.lo)) - imp * t3d;
-		acc[c] = ldexp(s, -ep.escale[c]);
-		if (c == CW) { Wm = W; T3m = T3; }
-	}
-	{
-		const HiLo B2 = mf_limbs(a0 + ep.col_b1, ep.climb[CW]);   // = 2 (T2 + T3), the plane holds 0/2
-		const HiLo H2 = hl(B2.hi / 2 - T3m.hi, B2.lo / 2 - T3m.lo);   // every limb sum of that plane is even
-		const double t3d = hl_to_double(T3m);
-		double w;
-		if (!h.minus) {
-			w = hl_to_double(hl_axpy(2, H2, Wm)) + imp * imp * t3d;
+		double r;
+		if (c != CW) {
+			double sm;
+			if (!minus) sm = hl_to_double(W) + imp * t3d;
+			else sm = hl_to_double(hl(2 * s_ftot[c][0] - W.hi, 2 * s_ftot[c][1] - W.lo)) - imp * t3d;
+			r = ldexp(sm, -s_col[c][2]);
 		} else {
-			const HiLo S1 = hl_axpy(-2, H2, Wm);
-			const HiLo R = hl(ep.ftot_hi[CW] - S1.hi - H2.hi - T3m.hi, ep.ftot_lo[CW] - S1.lo - H2.lo - T3m.lo);
-			w = hl_to_double(hl_axpy(4, R, S1)) + (2 - imp) * (2 - imp) * t3d;
+			const HiLo B2 = limbs(lb);                           // = 2 (T2 + T3), the plane holds 0/2
+			const HiLo H2 = hl(B2.hi / 2 - T3.hi, B2.lo / 2 - T3.lo);   // every limb sum of that plane is even
+			double w;
+			if (!minus) {
+				w = hl_to_double(hl_axpy(2, H2, W)) + imp * imp * t3d;
+			} else {
+				const HiLo S1 = hl_axpy(-2, H2, W);
+				const HiLo R = hl(s_ftot[CW][0] - S1.hi - H2.hi - T3.hi, s_ftot[CW][1] - S1.lo - H2.lo - T3.lo);
+				w = hl_to_double(hl_axpy(4, R, S1)) + (2 - imp) * (2 - imp) * t3d;
+			}
+			r = ldexp(w, -s_col[CW][2]);
 		}
-		acc[CW] = ldexp(w, -ep.escale[CW]);
+		s_acc[vl][c] = r;
 	}
+	__syncthreads();
+	// ---- 2. per variant
+	if (dbg & 4) return;
+	const int j = j0 + tid;
+	if (j >= M || !s_n[tid][3]) return;
+	const int n1 = s_n[tid][0], n2 = s_n[tid][1], n3 = s_n[tid][2];
+	const long long AC = (long long)n1 + 2ll * n2;
+	const VarHead h = make_head(md, (double)AC, N - n3);
+	const double imp = 2 * h.AF;
+	double *o = out8 + (size_t)j * 8;
+	double acc[P];
+#pragma unroll
+	for (int c = 0; c < P; c++) acc[c] = s_acc[tid][c];
 	if (ep.derive_c) {
 #pragma unroll
 		for (int x = 0; x < K; x++) {
@@ -878,6 +972,10 @@ score3_epilogue(int M, DevModel md, MfEpi ep, const int *__restrict__ accbuf, in
 		spa_push<K>(md, recs, counters, btop, fb_series, fb_exact, j, h.minus, h.minus ? (2 * h.Num - h.AC) : h.AC,
 			h.minus ? (N - n2) : (n1 + n2 + n3), h.lut, pn, Ssc, v2sc, cbuf);
 	}
-	atomicAdd(&counters[1], 1);
+	{
+		// one add per wave (50 000 adds of single lanes on this one address took 0.59 ms: ~12 ns each)
+		const unsigned long long act = __ballot(true);
+		if (__builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u)) == 0u) atomicAdd(&counters[1], (int)__popcll(act));
+	}
 }
 #endif /* S3_KERNEL_ONLY */

@@ -196,7 +196,8 @@ static int lists_bench(const uint8_t *rows, size_t bpv, int N, size_t M, int nti
 {
 	S3Lists L{};
 	const size_t cap = std::max<size_t>(M * std::max<size_t>(64, (size_t)N / 128), (size_t)S3_NSUB * 256);
-	L.idx_cap = (unsigned)cap; L.ld = M; L.nr = s3_nranges(ntile); L.nsub = (int)std::max<size_t>(1, std::min<size_t>(S3_NSUB, (M * (size_t)L.nr + 3) / 4));
+	L.idx_cap = (unsigned)cap; L.ld = M; L.nr = s3_nranges(ntile);
+	s3_lists_setup(L, ntile, (M * (size_t)L.nr + 3) / 4);
 	CK(hipMalloc((void **)&L.idx, cap * 4));
 	CK(hipMalloc((void **)&L.cursor, S3_NSUB * S3_CURSOR_STRIDE * 4));
 	CK(hipMalloc((void **)&L.lstart, S3_NR * M * 4)); CK(hipMalloc((void **)&L.lcnt, S3_NR * M * 4));
@@ -204,14 +205,14 @@ static int lists_bench(const uint8_t *rows, size_t bpv, int N, size_t M, int nti
 	uint8_t *copy = nullptr;
 	CK(hipMalloc((void **)&copy, M * bpv));
 	hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-	const unsigned grid = (unsigned)(((M + 3) / 4) * (size_t)L.nr);
+	const dim3 grid((unsigned)((M + 3) / 4), (unsigned)L.nr);
 	for (int mode = 0; mode < 2; mode++) {
 		float best = 1e30f;
 		for (int r = 0; r < reps + 1; r++) {
 			CK(hipMemset(L.cursor, 0, S3_NSUB * S3_CURSOR_STRIDE * 4));
 			CK(hipEventRecord(a, 0));
-			if (mode == 0) hipLaunchKernelGGL((s3_lists_kernel<8, false, false>), dim3(grid), dim3(256), 0, 0, rows, bpv, N, (int)M, 0, ntile, L, (uint8_t *)nullptr, (size_t)0);
-			else hipLaunchKernelGGL((s3_lists_kernel<8, true, true>), dim3(grid), dim3(256), 0, 0, rows, bpv, N, (int)M, 0, ntile, L, copy, bpv);
+			if (mode == 0) hipLaunchKernelGGL((s3_lists_kernel<8, false, false>), grid, dim3(256), 0, 0, rows, bpv, N, (int)M, 0, ntile, L, (uint8_t *)nullptr, (size_t)0);
+			else hipLaunchKernelGGL((s3_lists_kernel<8, true, true>), grid, dim3(256), 0, 0, rows, bpv, N, (int)M, 0, ntile, L, copy, bpv);
 			CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); CK(hipGetLastError());
 			float ms; CK(hipEventElapsedTime(&ms, a, b));
 			if (r > 0 || reps == 0) best = std::min(best, ms);
@@ -251,6 +252,103 @@ static int lists_bench(const uint8_t *rows, size_t bpv, int N, size_t M, int nti
 		printf("lists check N=%d M=%zu: %s\n", N, M, bad ? "FAILED" : "ok");
 	}
 	CK(hipFree(L.idx)); CK(hipFree(L.cursor)); CK(hipFree(L.lstart)); CK(hipFree(L.lcnt)); CK(hipFree(L.nzp)); CK(hipFree(L.n2p)); CK(hipFree(copy));
+	return bad;
+}
+
+// A stand-in for the other lane's cumulant pass: one workgroup of 512 threads per CU holding `lds` bytes of LDS and
+// ~2 NV registers per lane, busy with FP64 FMAs for `us` microseconds.  Beside it: how fast does the list pass go?
+template <int NV>
+__global__ void __launch_bounds__(512) occupy_kernel(double *out, unsigned long long ticks, double seed)
+{
+	extern __shared__ double occ_lds[];
+	double acc[NV];
+#pragma unroll
+	for (int i = 0; i < NV; i++) acc[i] = seed + i + threadIdx.x;
+	occ_lds[threadIdx.x] = seed;
+	const unsigned long long t0 = __builtin_readcyclecounter();
+	while (__builtin_readcyclecounter() - t0 < ticks) {
+#pragma unroll
+		for (int i = 0; i < NV; i++) acc[i] = __builtin_fma(acc[i], 1.0000001, acc[(i + 1) % NV] * 1e-9);
+	}
+	double sum = occ_lds[(threadIdx.x + 1) & 511];
+#pragma unroll
+	for (int i = 0; i < NV; i++) sum += acc[i];
+	if (sum == 12345.678) out[blockIdx.x] = sum;
+}
+
+template <int NV>
+static void beside(const char *what, size_t lds, int n_cu, hipStream_t s_occ, hipStream_t s_list, const uint8_t *rows, size_t bpv, int N, size_t M, int ntile, S3Lists L, int P, const long long *Q, long long *part, double *dummy)
+{
+	CK(hipFuncSetAttribute((const void *)occupy_kernel<NV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+	hipEvent_t a, b, c, d; CK(hipEventCreate(&a)); CK(hipEventCreate(&b)); CK(hipEventCreate(&c)); CK(hipEventCreate(&d));
+	for (int order = 0; order < 2; order++) {
+		CK(hipDeviceSynchronize());
+		const unsigned long long ticks = 100000000ull * 8 / 10000;      // 0.8 ms at the 100 MHz of s_memrealtime... (readcyclecounter: shader clock; see the printed time)
+		auto occ = [&]() { CK(hipEventRecord(a, s_occ)); hipLaunchKernelGGL((occupy_kernel<NV>), dim3(n_cu), dim3(512), lds, s_occ, dummy, ticks * 21, 1.0); CK(hipEventRecord(b, s_occ)); };
+		auto lst = [&]() { CK(hipEventRecord(c, s_list)); hipLaunchKernelGGL((s3_lists_t3_kernel<8, 8>), dim3((unsigned)((M + 3) / 4), (unsigned)L.nr), dim3(256), 0, s_list, rows, bpv, N, (int)M, ntile, L, P, Q, part); CK(hipEventRecord(d, s_list)); };
+		if (order == 0) { occ(); lst(); } else { lst(); occ(); }
+		CK(hipDeviceSynchronize()); CK(hipGetLastError());
+		float mo, ml; CK(hipEventElapsedTime(&mo, a, b)); CK(hipEventElapsedTime(&ml, c, d));
+		printf("beside %-34s (%s first): stand-in %6.3f ms, list pass %6.3f ms\n", what, order ? "list" : "stand-in", mo, ml);
+	}
+}
+
+// the fused list + T3 pass of row-major calls (kern_lists.h): timing, counts and sums against a CPU walk
+template <int PP>
+static int lists_t3_bench(const uint8_t *rows, size_t bpv, int N, size_t M, int ntile, int reps, bool verify, int P)
+{
+	S3Lists L{};
+	L.ld = M; L.nr = s3_nranges(ntile);
+	s3_lists_setup(L, ntile, (M * (size_t)L.nr + 3) / 4);
+	CK(hipMalloc((void **)&L.lcnt, S3_NR * M * 4));
+	long long *Q, *part;
+	const size_t nq = (size_t)ntile * 256 * P;
+	CK(hipMalloc((void **)&Q, nq * 8));
+	CK(hipMalloc((void **)&part, (size_t)L.nr * M * P * 2 * 8));
+	std::vector<long long> hq(nq);
+	{ uint64_t x = 99; for (auto &v : hq) v = (long long)(sm64(x) >> 8) - (1ll << 55); }
+	CK(hipMemcpy(Q, hq.data(), nq * 8, hipMemcpyHostToDevice));
+	hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+	const unsigned grid = (unsigned)(((M + 3) / 4) * (size_t)L.nr);
+	int bad = 0;
+	for (int mode = 0; mode < 1; mode++) {
+		float best = 1e30f;
+		CK(hipMemset(part, 0xEE, (size_t)L.nr * M * P * 2 * 8));
+		for (int r = 0; r < reps + 1; r++) {
+			CK(hipEventRecord(a, 0));
+			hipLaunchKernelGGL((s3_lists_t3_kernel<8, PP>), dim3((unsigned)((M + 3) / 4), (unsigned)L.nr), dim3(256), 0, 0, rows, bpv, N, (int)M, ntile, L, P, Q, part);
+			CK(hipEventRecord(b, 0)); CK(hipEventSynchronize(b)); CK(hipGetLastError());
+			float ms; CK(hipEventElapsedTime(&ms, a, b));
+			if (r > 0 || reps == 0) best = std::min(best, ms);
+		}
+		printf("list + T3 pass N=%d M=%zu P=%d: %7.3f ms  %6.0f GB/s read\n", N, M, P, best, (double)M * ntile * 64 / best / 1e6);
+		if (!verify) continue;
+		std::vector<uint8_t> hr(M * bpv);
+		CK(hipMemcpy(hr.data(), rows, M * bpv, hipMemcpyDeviceToHost));
+		std::vector<int> cn((size_t)L.nr * M);
+		std::vector<long long> hp((size_t)L.nr * M * P * 2);
+		CK(hipMemcpy(cn.data(), L.lcnt, cn.size() * 4, hipMemcpyDeviceToHost));
+		CK(hipMemcpy(hp.data(), part, hp.size() * 8, hipMemcpyDeviceToHost));
+		size_t over = 0;
+		for (size_t v = 0; v < M && bad < 5; v++)
+			for (int g = 0; g < L.nr; g++) {
+				const int s0 = s3_range_t0(g, ntile, L.nr) * 256, s1 = std::min(N, s3_range_t0(g + 1, ntile, L.nr) * 256);
+				std::vector<long long> hi(P, 0), lo(P, 0);
+				int want = 0;
+				for (int s = s0; s < s1; s++)
+					if (((hr[v * bpv + s / 4] >> (2 * (s % 4))) & 3) == 3) {
+						want++;
+						for (int c = 0; c < P; c++) { const long long q = hq[(size_t)s * P + c]; hi[c] += q >> 32; lo[c] += q & 0xFFFFFFFFll; }
+					}
+				const size_t e = (size_t)g * M + v;
+				if (want > S3_LT_CAP) { over++; if (cn[e] != -1) { fprintf(stderr, "list+T3: variant %zu range %d: %d entries, count %d (want -1)\n", v, g, want, cn[e]); bad++; } continue; }
+				bool ok = cn[e] == want;
+				for (int c = 0; ok && c < P; c++) ok = hp[(e * P + c) * 2] == hi[c] && hp[(e * P + c) * 2 + 1] == lo[c];
+				if (!ok) { fprintf(stderr, "list+T3: variant %zu range %d: count %d want %d, or sums differ\n", v, g, cn[e], want); bad++; }
+			}
+		printf("list + T3 check N=%d M=%zu P=%d (%zu segments beyond the cap): %s\n", N, M, P, over, bad ? "FAILED" : "ok");
+	}
+	CK(hipFree(L.lcnt)); CK(hipFree(Q)); CK(hipFree(part));
 	return bad;
 }
 
@@ -359,6 +457,51 @@ int main(int argc, char **argv)
 			CK(hipFree(Sm));
 			if (badl) return 1;
 			lists_bench(Ar, bpv, N, M, ntile, reps, false);
+			if (getenv("LT3")) {
+				// small shapes against the CPU (ragged N, a long-range shape, dense missing codes), then the timing
+				const int mrates[3] = {66, 655, 6000};
+				for (int q = 0; q < 3; q++) {
+					const int n4 = 70001 + 4099 * q, nt4 = 2 * ((n4 + 511) / 512); const size_t m4 = 131, bp4 = (size_t)nt4 * 64 + 128;
+					CK(hipMalloc((void **)&Sm, m4 * bp4));
+					fill_codes<<<256, 256>>>((uint32_t *)Sm, m4 * bp4 / 4, 900 + q, mrates[q]);
+					CK(hipDeviceSynchronize());
+					badl += lists_t3_bench<8>(Sm, bp4, n4, m4, nt4, 0, true, 8);
+					badl += lists_t3_bench<16>(Sm, bp4, n4, m4, nt4, 0, true, 12);
+					badl += lists_t3_bench<32>(Sm, bp4, n4, m4, nt4, 0, true, 28);
+					badl += lists_t3_bench<64>(Sm, bp4, n4, m4, nt4, 0, true, 34);
+					CK(hipFree(Sm));
+				}
+				{
+					const int n5 = 600000, nt5 = 2 * ((n5 + 511) / 512); const size_t m5 = 24, bp5 = (size_t)nt5 * 64;
+					CK(hipMalloc((void **)&Sm, m5 * bp5));
+					fill_codes<<<256, 256>>>((uint32_t *)Sm, m5 * bp5 / 4, 779, 20);
+					CK(hipDeviceSynchronize());
+					badl += lists_t3_bench<8>(Sm, bp5, n5, m5, nt5, 0, true, 8);
+					CK(hipFree(Sm));
+				}
+				if (badl) return 1;
+				lists_t3_bench<8>(Ar, bpv, N, M, ntile, reps, false, 8);
+				lists_t3_bench<32>(Ar, bpv, N, M, ntile, reps, false, 28);
+				if (getenv("BESIDE")) {
+					S3Lists L{};
+					L.ld = M; L.nr = s3_nranges(ntile);
+					s3_lists_setup(L, ntile, (M * (size_t)L.nr + 3) / 4);
+					CK(hipMalloc((void **)&L.lcnt, S3_NR * M * 4));
+					long long *Q, *part; double *dummy;
+					CK(hipMalloc((void **)&Q, (size_t)ntile * 256 * 8 * 8)); CK(hipMemset(Q, 1, (size_t)ntile * 256 * 8 * 8));
+					CK(hipMalloc((void **)&part, (size_t)L.nr * M * 8 * 2 * 8)); CK(hipMalloc((void **)&dummy, 4096 * 8));
+					hipStream_t so, sl; int lo, hi; CK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+					const int mode = atoi(getenv("BESIDE"));      // 1: stand-in low / list high priority, 2: both normal, 3: stand-in high / list low
+					CK(hipStreamCreateWithPriority(&so, hipStreamNonBlocking, mode == 1 ? lo : mode == 3 ? hi : 0)); CK(hipStreamCreateWithPriority(&sl, hipStreamNonBlocking, mode == 1 ? hi : mode == 3 ? lo : 0));
+					printf("priorities: range %d (low) .. %d (high), mode %d\n", lo, hi, mode);
+					beside<46>("186 regs, 154 KiB LDS", 154 * 1024, n_cu, so, sl, Ar, bpv, N, M, ntile, L, 8, Q, part, dummy);
+					beside<46>("186 regs, 128 KiB LDS", 128 * 1024, n_cu, so, sl, Ar, bpv, N, M, ntile, L, 8, Q, part, dummy);
+					beside<46>("186 regs, 8 KiB LDS", 8 * 1024, n_cu, so, sl, Ar, bpv, N, M, ntile, L, 8, Q, part, dummy);
+					beside<28>("64 regs, 154 KiB LDS", 154 * 1024, n_cu, so, sl, Ar, bpv, N, M, ntile, L, 8, Q, part, dummy);
+					beside<28>("64 regs, 8 KiB LDS", 8 * 1024, n_cu, so, sl, Ar, bpv, N, M, ntile, L, 8, Q, part, dummy);
+				}
+				return 0;
+			}
 		}
 #define R0(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, name) run<NBF, NAF, NC, NLA, NLB, DA, DB, ABL, 1, 2, 0>(name, A, Fl, ntile, M, 1, n_cu, out, oints, reps)
 #define R1(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, name) run<NBF, NAF, NC, NLA, NLB, DA, DB, ABL, 1, 2, 1>(name, Ar, Fl, ntile, M, 1, n_cu, out, oints, reps, nullptr, bpv)
