@@ -36,6 +36,7 @@ HBM_PEAK_GBS = 8000.0
 CLOCK_HZ = 2.4e9
 MFMA_CYCLES, MFMA_ISSUE, VALU_ISSUE = 16, 8, 4
 UNPACK_OPS = 9              # vector instructions per (16 variants x 16 samples) dword of score3_kernel (kern_score3.h)
+UNPACK_OPS_3 = 16           # ... of its three-plane form (s3_unpack3_op), which also has 2 nbf - 1 MFMAs per dword instead of nbf
 BOUND_NAME = {"hbm": "hbm", "mfma": "mfma", "valu_issue": "valu issue"}
 
 WORKLOADS = {
@@ -150,20 +151,20 @@ class Case:
             b.close()
         self.sc.close()
 
-    def bounds(self, n_cu=256):
-        """(algorithmic bytes per launch, the three rooflines of score3_kernel for this configuration)"""
+    def bounds(self, n_cu=256, three_plane=False):
+        """(algorithmic bytes per launch, the three rooflines of score3_kernel for this configuration and form)"""
         nfrag, ntile = (self.block + 15) // 16, 2 * ((self.n + 511) // 512)
         row_bytes = math.ceil(self.n / 4)
         alg = self.block * (row_bytes + 64)                       # SURVEY 8(d): ceil(N/4) + 64 B per variant
         dwords = nfrag * ntile * 4                                # (16 variants x 16 samples) units
-        n_mfma = dwords * self.nbf
-        n_valu = dwords * UNPACK_OPS
+        n_mfma = dwords * (2 * self.nbf - 1 if three_plane else self.nbf)
+        n_valu = dwords * (UNPACK_OPS_3 if three_plane else UNPACK_OPS)
         simd_hz = n_cu * 4 * CLOCK_HZ
         return alg, {
             "hbm_ms": round(alg / (HBM_PEAK_GBS * 1e9) * 1e3, 4),
             "mfma_ms": round(n_mfma * MFMA_CYCLES / simd_hz * 1e3, 4),
             "valu_issue_ms": round((n_valu * VALU_ISSUE + n_mfma * MFMA_ISSUE) / simd_hz * 1e3, 4),
-            "mfma_per_launch": n_mfma, "valu_per_launch": n_valu, "b_fragments": self.nbf,
+            "mfma_per_launch": n_mfma, "valu_per_launch": n_valu, "b_fragments": self.nbf, "form": "three planes" if three_plane else "two planes",
             "rates": "8 TB/s; v_mfma_i32_16x16x64_i8 16 cycles per SIMD (8 of them holding the vector issue port), "
                      "other vector instructions 4 issue cycles; 1024 SIMDs at 2.4 GHz (MI355X_MICROARCH.md)",
         }
@@ -346,7 +347,8 @@ def main():
     n_valid = int(tot["n_valid"])
     nv_tot = steps * block
     row_bytes = math.ceil(n / 4)
-    alg_bytes, bounds = case.bounds()
+    three_plane = tot.get("three_plane", 0) * 2 > steps       # the form the steps took (row-major calls: up to 4 B fragments, or many missing genotypes)
+    alg_bytes, bounds = case.bounds(three_plane=three_plane)
     # The kernel that streams the algorithmic bytes is score3_kernel (ONE launch per step, any K).  The SPA
     # stage re-reads only the rows of the flagged variants; it is FP64-issue-bound, not HBM-bound, and is
     # reported as a stage beside it.
@@ -366,9 +368,20 @@ def main():
     spa_alg = n_spa / max(1, steps) * row_bytes      # rows of the flagged variants, read once more
     whole_gbs = alg_bytes * steps / elapsed / 1e9
     binding = max(("hbm", "mfma", "valu_issue"), key=lambda b: bounds[b + "_ms"])
+    # The roofline that binds: HBM (two-plane form at K = 3: GB/s of algorithmic bytes), or the matrix pipe / vector issue
+    # of the contraction (the three-plane form, wide models: int8 MFMA operations per second against the dense peak
+    # -- v_mfma_i32_16x16x64_i8 at 16 cycles per SIMD = 2 x the BF16 rate, MI355X_MICROARCH.md)
+    mfma_ops = bounds["mfma_per_launch"] * 16 * 16 * 64 * 2
+    mfma_peak_tops = 256 * 4 * CLOCK_HZ / MFMA_CYCLES * (16 * 16 * 64 * 2) / 1e12
+    mfma_achieved = mfma_ops / (ms_kernel * 1e-3) / 1e12
+    by_hbm = binding == "hbm"
     roofline = {
-        "bound": BOUND_NAME[binding], "kernel": score_kernel, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+        "bound": "hbm" if by_hbm else "mfma", "binding": BOUND_NAME[binding],
+        "kernel": score_kernel, "achieved": round(achieved if by_hbm else mfma_achieved, 2), "peak": HBM_PEAK_GBS if by_hbm else round(mfma_peak_tops, 1),
+        "unit": "GB/s" if by_hbm else "TFLOP/s", "frac": round(achieved / HBM_PEAK_GBS if by_hbm else mfma_achieved / mfma_peak_tops, 5),
+        "unit_note": None if by_hbm else "int8 multiply-adds of v_mfma_i32_16x16x64_i8 (2 per MAC), exact integer arithmetic; dense peak",
+        "hbm": {"achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5)},
+        "traffic": traffic, "traffic_source": traffic_src,
         "bounds": bounds, "frac_of_binding": round(bounds[binding + "_ms"] / ms_kernel, 5),
         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(ms_kernel, 4),
         "launch_ms_note": "HIP events right before and after the launch of score3_kernel on the library's stream, averaged over "
@@ -385,9 +398,9 @@ def main():
         "stages": {
             "lists": {"avg_ms": round(ms_lists, 4), "kernel": "s3_lists_t3_kernel", "algorithmic_bytes": block * row_bytes,
                       "frac_of_hbm_peak": round(block * row_bytes / (max(ms_lists, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": "hbm",
-                      "note": "one read of the rows: finds the missing genotypes and gathers their score vectors on the spot (the sparse "
-                              "pass of the two-plane form; 0 where a step took the three-plane form); the rows are read twice per "
-                              "step: here and by score3_kernel"},
+                      "note": "the two-plane form's pass over the rows (finds the missing genotypes and gathers their score vectors on the "
+                              "spot: the rows are then read twice per step); 0 where the steps took the three-plane form -- up to 4 B "
+                              "fragments (K = 3 binary) always, else from ~0.5 % missing genotypes -- which reads the rows once"},
             "score": {"avg_ms": round(ms_score, 4), "launches_per_step": int(tot["score_launches"] // steps),
                       "algorithmic_bytes": alg_bytes, "hbm_bytes": traffic, "bound": BOUND_NAME[binding],
                       "frac_of_hbm_peak": round(alg_bytes / (ms_score * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
@@ -562,7 +575,7 @@ def main():
                                     ("c3_missing_1e-2", "c3", 3, 1e-2), ("c3_missing_2e-2", "c3", 3, 2e-2)):
             c2 = Case(w2, k2, block, args.seed, min(args.pool_gb, 24.0), 4, rank, local, miss_rate=miss2)
             r2 = measure(c2, 12, 3, args.lanes)
-            alg2, b2 = c2.bounds()
+            alg2, b2 = c2.bounds(three_plane=r2["tot"].get("three_plane", 0) * 2 > 12)
             ms2 = r2["tot"]["ms_score"] / 12
             mk2 = r2["tot"]["ms_kernel"] / 12
             bind2 = max(("hbm", "mfma", "valu_issue"), key=lambda b: b2[b + "_ms"])
@@ -571,9 +584,9 @@ def main():
                 "ms_per_step": round(r2["elapsed"] / 12 * 1e3, 3), "steps": 12,
                 "kernel_ms": round(mk2, 4), "lists_ms": round(r2["tot"]["ms_lists"] / 12, 4), "score_stage_ms": round(ms2, 4),
                 "spa_stage_ms": round(r2["tot"]["ms_spa"] / 12, 4), "missing_rate": miss2,
-                "frac": round(alg2 / (mk2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": BOUND_NAME[bind2],
+                "frac": round(alg2 / (mk2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": "hbm" if bind2 == "hbm" else "mfma", "binding": BOUND_NAME[bind2],
                 "frac_of_binding": round(b2[bind2 + "_ms"] / mk2, 5),
-                "bounds": {k: b2[k] for k in ("hbm_ms", "mfma_ms", "valu_issue_ms", "b_fragments")},
+                "bounds": {k: b2[k] for k in ("hbm_ms", "mfma_ms", "valu_issue_ms", "b_fragments", "form")},
                 "whole_step_frac": round(alg2 * 12 / r2["elapsed"] / 1e9 / HBM_PEAK_GBS, 5),
             }
             c2.close()

@@ -109,9 +109,10 @@ typedef struct sgx_stats {
 	uint32_t spa_launches;
 	float ms_kernel;       /* HIP-event time of the genotype-streaming kernel alone (score3_kernel), ms;
 	                          0 where the scan took the FP64 kernels                                      */
-	float ms_lists;        /* row-major calls: HIP-event time of the pass that lists the missing genotypes
-	                          (in front of the score stage; part of ms_total, not of ms_score); 0 for
-	                          sgx_scan_block, whose lists were made when the block was loaded            */
+	float ms_lists;        /* row-major calls on the two-plane form: HIP-event time of the pass that finds the
+	                          missing genotypes (in front of the score stage; part of ms_total, not of
+	                          ms_score); 0 for the three-plane form and for sgx_scan_block, whose lists were
+	                          made when the block was loaded                                             */
 	uint32_t three_plane;  /* 1: the call took the three-plane form of the contraction kernel (the sums over the
 	                          missing samples from a third MFMA plane: no lists, no sparse pass; chosen for
 	                          few score columns or many missing genotypes); totals: number of such calls     */
@@ -247,8 +248,9 @@ int sgx_geno_stats_2bit(const uint8_t *packed, size_t bytes_per_variant, int32_t
  * their own workspace, so the SPA stage of one block runs under the score stage of the next; call
  * sgx_sync() before reading any output), "pipe_mb" (MiB of input rows per chunk of a host-buffer scan;
  * 0 = default 512), "spa_abl" (diagnostic bits; 512: the SPA kernels scan the rows of a block instead of
- * walking its carrier lists), "three_plane" (-1 automatic, 0 / 1: never / always the three-plane form of the
- * contraction kernel), "guard_exp" (x: the fixed-point guard at 10^-x instead of 2e-11; 0 = off, 300 = every
+ * walking its carrier lists), "three_plane" (-1 automatic -- row-major calls take the three-plane form of the
+ * contraction kernel for models of up to four B fragments (K <= 3 binary, any quantitative K <= 2) and otherwise once
+ * more than ~0.5 % of the genotypes are missing, resident blocks by the census of their load; 0 / 1: never / always), "guard_exp" (x: the fixed-point guard at 10^-x instead of 2e-11; 0 = off, 300 = every
  * variant through the FP64 kernel).  Results never depend on them beyond rounding (1e-12). */
 int sgx_set_option(sgx_handle *h, const char *name, long long value);
 

@@ -226,17 +226,20 @@ extern "C" int sgx_scan_block(sgx_handle *h, const sgx_block *b, double *out8_de
 	return launch_block_scan(lane, b, b->M, out8_dev, valid_dev, true, miss);
 }
 
-// Which form of the contraction kernel a call takes.  The two-plane form needs the positions of the missing genotypes
-// (a pass over the rows, or a resident block's lists) and a sparse pass whose cost grows with their number; the
-// three-plane form needs neither, at ~1.7 x the MFMAs.  Measured (tools/README.md, round 4): up to 3 B fragments
-// (quantitative traits, K <= 2) the three-plane kernel costs what the two-plane kernel does and saves the list pass;
-// from 4 fragments on it pays once more than ~0.5 % of the genotypes are missing -- where the sparse pass has grown
-// to the difference and the pool of the lists (0.8 %) is about to overflow.
+// Which form of the contraction kernel a row-major call takes.  The two-plane form needs the positions of the missing
+// genotypes -- a pass over the rows (s3_lists_t3_kernel) whose cost grows with their number; the three-plane form needs
+// none, at ~1.7 x the MFMAs.  Large kernels of different streams do not share the machine (tools/README.md, round 4: a
+// kernel that holds every CU keeps the other queue's out), so what counts is the sum of the two kernels' times:
+//   K = 3 binary (4 B fragments), N = 430 000: list pass 0.89 + two planes 1.04 ms against three planes 1.55-1.75 ms:
+//     step 3.19-3.23 -> 2.88-3.01 ms (same box), N = 50 000: 0.676 -> 0.620; K = 2: 3.11 -> 2.84
+//   K = 4 (5 fragments): 3.56 against 3.63, K = 5: 3.94 against 4.02 ms: the two-plane form, until more than ~0.5 % of
+//     the genotypes are missing -- where the sparse sums have grown to the difference and the segments' room
+//     (S3_LT_CAP entries) is about to overflow.
 static bool rows_take_three_planes(const sgx_handle *lane)
 {
 	const sgx_handle *p = lane->owner ? lane->owner : lane;
 	if (p->dense_opt >= 0) return p->dense_opt != 0;
-	return lane->mf_nbfv[0] + 1 <= 3 || p->dense_mode;
+	return lane->mf_nbfv[0] + 1 <= 4 || p->dense_mode;
 }
 
 // the lists of this lane's row-major calls (the rows stay where the caller has them)

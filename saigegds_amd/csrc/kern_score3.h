@@ -46,6 +46,9 @@ __device__ __forceinline__ void s3_static_for(F &&f)
 	if constexpr (I < N) { f(std::integral_constant<int, I>()); s3_static_for<I + 1, N>(f); }
 }
 
+#ifndef S3_AUX_ROWS
+#define S3_AUX_ROWS 2            /* cache policy of the row loaders' DMA: nt (streaming) -- the rows are read once and should not push the B tiles (L2) out; 1-6 % by form, tools/README.md */
+#endif
 #define S3_WAITCNT_VM(n) __builtin_amdgcn_s_waitcnt(((n) & 0xF) | (((n) >> 4) << 14) | (0x7 << 4) | (0xF << 8))
 
 // Unpack of one dword (16 codes) of a row piece into the two A operands (4 dwords each), as micro-operations
@@ -200,7 +203,7 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 #pragma unroll
 					for (int h = 0; h < 2; h++)
 						__builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void *)(s3_smem + RB * TILE_BYTES + sl * SLOT_A + (2 * p + h) * 1024),
-							16, (int)(pp == lastf ? vol[h] : vo[h]), so, 0, 0);
+							16, (int)(pp == lastf ? vol[h] : vo[h]), so, 0, S3_AUX_ROWS);
 				}
 				sl = sl + 1 == RA ? 0 : sl + 1;
 				pos_next(pa); pos_next(pa);
@@ -700,17 +703,6 @@ s3_t3_kernel(int M, int P, const long long *__restrict__ Q, S3Lists L, long long
 		long long *o = part + (((size_t)g * M + v) * P + c) * 2;
 		o[0] = hi; o[1] = lo;
 	}
-}
-
-// sums of the per-range partials: t3[v][c] = {hi, lo}
-__global__ void __launch_bounds__(256)
-s3_t3_sum_kernel(size_t n, int nr, const long long *__restrict__ part, long long *__restrict__ t3)
-{
-	const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;      // over M x P x 2
-	if (i >= n) return;
-	long long s = 0;
-	for (int g = 0; g < nr; g++) s += part[(size_t)g * n + i];
-	t3[i] = s;
 }
 
 // ---- the item slabs of score3_kernel -> one row of limb sums per variant (the layout the epilogue reads:

@@ -431,42 +431,50 @@ def test_three_plane_form_equals_two_plane_form(trait, k, miss):
 
 
 def test_missing_rate_picks_the_form():
-    """Automatic choice: a binary model with K = 3 starts on the two-plane form (lists of the missing genotypes);
-    a step that finds more than 0.5 % of its genotypes missing turns the following row-major calls to the
-    three-plane form, a three-plane step with few missing genotypes turns them back; resident blocks decide from
-    the census of their own load.  Tables are the oracle's either way."""
+    """Automatic choice for row-major calls: models of up to four B fragments always take the three-plane form; a wider
+    model starts on the two-plane form (lists of the missing genotypes), a step that finds more than 0.5 % of its
+    genotypes missing turns the following calls to the three-plane form, a three-plane step with few missing
+    genotypes turns them back; resident blocks decide from the census of their own load.  Tables are the oracle's
+    either way."""
     import torch
     from saigegds_amd._lib import Block
     dev = torch.device("cuda", 0)
-    sm, dirty = _synthetic_case(3001, 800, "binary", 0.05, seed=59, miss=0.03)
-    _, clean = _synthetic_case(3001, 800, "binary", 0.05, seed=59, miss=1e-3)
-    orc = _oracle(sm)
-    with _scanner(sm) as sc, Block(sm.n, 800) as b_dirty, Block(sm.n, 800) as b_clean:
-        bpv = sc.row_stride()
+    seen = set()
+    for trait, k in (("binary", 5), ("binary", 3), ("quantitative", 3)):
+        sm, dirty = _synthetic_case(3001, 800, trait, 0.05, seed=59, k=k, miss=0.03)
+        _, clean = _synthetic_case(3001, 800, trait, 0.05, seed=59, k=k, miss=1e-3)
+        orc = _oracle(sm)
+        with _scanner(sm) as sc, Block(sm.n, 800) as b_dirty, Block(sm.n, 800) as b_clean:
+            limbs, ngroups = sc.score_layout()
+            nbf = (int(limbs.sum()) + 1 + 15) // 16 + 1          # B fragments: value columns + constant, and the bit-1 fragment
+            narrow = nbf <= 4
+            seen.add(narrow)
+            bpv = sc.row_stride()
 
-        def dev_rows(p):
-            t = torch.zeros((800, bpv), dtype=torch.uint8, device=dev)
-            t[:, :p.shape[1]] = torch.from_numpy(p).to(dev)
-            return t
+            def dev_rows(p):
+                t = torch.zeros((800, bpv), dtype=torch.uint8, device=dev)
+                t[:, :p.shape[1]] = torch.from_numpy(p).to(dev)
+                return t
 
-        rows = {"dirty": dev_rows(dirty), "clean": dev_rows(clean)}
-        out = torch.zeros((800, 8), dtype=torch.float64, device=dev)
-        valid = torch.zeros(800, dtype=torch.uint8, device=dev)
-        torch.cuda.synchronize()
-        seq = [("dirty", 0), ("dirty", 1), ("clean", 1), ("clean", 0), ("clean", 0)]
-        for name, want in seq:
-            sc.scan_2bit_dev(rows[name].data_ptr(), bpv, 800, out.data_ptr(), valid.data_ptr())
-            st = sc.stats()
-            assert st["three_plane"] == want, (name, want, st)
-            ref, ref_valid = orc.scan_2bit(dirty if name == "dirty" else clean)
-            assert_table_close(out.cpu().numpy(), valid.cpu().numpy(), ref, ref_valid, what=f"{name} rows, three_plane={want}")
-        sc.load_block(b_dirty, dirty)
-        sc.load_block(b_clean, clean)
-        for blk, p, want in ((b_dirty, dirty, 1), (b_clean, clean, 0)):
-            o, v = _scan_block(sc, blk, 800)
-            assert sc.stats()["three_plane"] == want
-            ref, ref_valid = orc.scan_2bit(p)
-            assert_table_close(o, v, ref, ref_valid, what=f"block, three_plane={want}")
+            rows = {"dirty": dev_rows(dirty), "clean": dev_rows(clean)}
+            out = torch.zeros((800, 8), dtype=torch.float64, device=dev)
+            valid = torch.zeros(800, dtype=torch.uint8, device=dev)
+            torch.cuda.synchronize()
+            for name, wide_want in [("dirty", 0), ("dirty", 1), ("clean", 1), ("clean", 0), ("clean", 0)]:
+                want = 1 if narrow else wide_want
+                sc.scan_2bit_dev(rows[name].data_ptr(), bpv, 800, out.data_ptr(), valid.data_ptr())
+                st = sc.stats()
+                assert st["three_plane"] == want, (trait, k, nbf, name, want, st)
+                ref, ref_valid = orc.scan_2bit(dirty if name == "dirty" else clean)
+                assert_table_close(out.cpu().numpy(), valid.cpu().numpy(), ref, ref_valid, quant=sm.quant, what=f"{trait} K={k} {name} rows, three_plane={want}")
+            sc.load_block(b_dirty, dirty)
+            sc.load_block(b_clean, clean)
+            for blk, p, want in ((b_dirty, dirty, 1), (b_clean, clean, 0)):
+                o, v = _scan_block(sc, blk, 800)
+                assert sc.stats()["three_plane"] == want
+                ref, ref_valid = orc.scan_2bit(p)
+                assert_table_close(o, v, ref, ref_valid, quant=sm.quant, what=f"block, three_plane={want}")
+    assert seen == {True, False}, seen      # both rules were exercised
 
 
 def _uncentred_model(n, trait, seed=5):

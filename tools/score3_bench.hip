@@ -523,6 +523,34 @@ int main(int argc, char **argv)
 		R3M(4, 2, 8, 2, 2, 2, 2, 0, "k3 three planes naf2 8+2+2 d2/2");
 		R3M(4, 4, 4, 3, 1, 2, 2, 0, "k3 three planes naf4 4+3+1 d2/2");
 		R3M(4, 2, 8, 3, 1, 2, 2, 1, "k3 three planes naf2 memory only");
+		if (getenv("SWEEP3")) {
+			R3M(4, 3, 8, 3, 1, 1, 1, 0, "k3 three planes naf3 8+3+1 d1/1");
+			R3M(4, 3, 8, 3, 1, 1, 2, 0, "k3 three planes naf3 8+3+1 d1/2");
+			R3M(4, 3, 8, 2, 2, 1, 1, 0, "k3 three planes naf3 8+2+2 d1/1");
+			R3M(4, 4, 4, 2, 2, 2, 2, 0, "k3 three planes naf4 4+2+2 d2/2");
+			R3M(4, 4, 4, 3, 1, 3, 2, 0, "k3 three planes naf4 4+3+1 d3/2");
+			R3M(4, 2, 8, 3, 1, 3, 1, 0, "k3 three planes naf2 8+3+1 d3/1");
+			R3M(4, 2, 12, 3, 1, 1, 1, 0, "k3 three planes naf2 12+3+1 d1/1");
+			R3M(4, 3, 4, 3, 1, 2, 2, 0, "k3 three planes naf3 4+3+1 d2/2");
+			R3M(4, 4, 8, 3, 1, 1, 1, 0, "k3 three planes naf4 8+3+1 d1/1");
+		}
+		if (getenv("SWEEP4")) {
+			int badc = 0;
+			badc += check<4, 4, 5, 2, 1, 2, 1, 1, 2, 1, true>("three planes naf4 5+2+1", 2300, 777, 1, 8, 64);
+			badc += check<4, 4, 6, 1, 1, 1, 2, 1, 2, 1, true>("three planes naf4 6+1+1", 2300, 777, 1, 8, 64);
+			badc += check<4, 2, 8, 2, 2, 2, 2, 1, 2, 1, true>("three planes naf2 8+2+2", 2300, 777, 1, 8, 64);
+			if (badc) return 1;
+			R3M(4, 2, 8, 2, 2, 2, 2, 0, "k3 three planes naf2 8+2+2 d2/2");
+			R3M(4, 4, 5, 2, 1, 2, 1, 0, "k3 three planes naf4 5+2+1 d2/1");
+			R3M(4, 4, 5, 2, 1, 1, 2, 0, "k3 three planes naf4 5+2+1 d1/2");
+			R3M(4, 4, 6, 1, 1, 1, 2, 0, "k3 three planes naf4 6+1+1 d1/2");
+			R3M(4, 4, 6, 1, 1, 1, 1, 0, "k3 three planes naf4 6+1+1 d1/1");
+			R3M(4, 4, 4, 2, 2, 2, 1, 0, "k3 three planes naf4 4+2+2 d2/1");
+			R3M(4, 4, 4, 3, 1, 2, 1, 0, "k3 three planes naf4 4+3+1 d2/1");
+			R3M(4, 2, 8, 2, 2, 2, 1, 0, "k3 three planes naf2 8+2+2 d2/1");
+			R3M(4, 2, 8, 2, 2, 3, 1, 0, "k3 three planes naf2 8+2+2 d3/1");
+			return 0;
+		}
 		R3M(2, 4, 8, 3, 1, 1, 2, 0, "quant three planes naf4");
 		R3M(6, 3, 4, 2, 2, 2, 1, 0, "k5 three planes naf3 4+2+2");
 		R3M(12, 1, 4, 2, 2, 2, 1, 0, "k13 three planes naf1 4+2+2");
