@@ -8,11 +8,6 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$R
 mkdir -p $OUT
 export TMPDIR=/tmp
-python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
-echo "bench done"
-for w in c2 c4; do python3 bench.py --workload $w --cpu-seconds 0 --host-variants 0 --file-variants 0 --secondary 0 > $OUT/bench_$w.json 2> $OUT/bench_$w.err; done
-for k in 5 8 13 16; do python3 bench.py --k $k --cpu-seconds 0 --host-variants 0 --file-variants 0 --secondary 0 --resident-steps 0 > $OUT/bench_k$k.json 2> $OUT/bench_k$k.err; done
-echo "configs done"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof2 -- python3 $ROOT/bench.py --steps 20 --warmup 2 --cpu-seconds 0 --host-variants 0 --file-variants 0 --secondary 0 --resident-steps 0 > $OUT/bench_under_rocprof.json 2> $OUT/prof2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof1 -- python3 $ROOT/bench.py --steps 20 --warmup 2 --cpu-seconds 0 --host-variants 0 --file-variants 0 --secondary 0 --resident-steps 0 --lanes 1 > $OUT/bench_under_rocprof_one_lane.json 2> $OUT/prof1.err
@@ -24,6 +19,13 @@ rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 echo "pmc done"
 cd $ROOT
 python3 profiles/digest_pmc.py $OUT/pmc_rd $OUT/pmc_wr 5 $OUT/pmc_stages.json workload=c3 trait=binary n_samples=430000 variants_per_launch=50000 n_covariates=3 > $OUT/pmc_digest.txt
+# (the bench line quotes the traffic of THIS build: the digest goes where bench.py looks for it before the line is made)
+cp $OUT/pmc_stages.json profiles/${R}_pmc_stages.json
+python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+echo "bench done"
+for w in c2 c4; do python3 bench.py --workload $w --cpu-seconds 0 --host-variants 0 --file-variants 0 --secondary 0 > $OUT/bench_$w.json 2> $OUT/bench_$w.err; done
+for k in 5 8 13 16; do python3 bench.py --k $k --cpu-seconds 0 --host-variants 0 --file-variants 0 --secondary 0 --resident-steps 0 > $OUT/bench_k$k.json 2> $OUT/bench_k$k.err; done
+echo "configs done"
 python3 profiles/show_pmc.py $OUT/pmc_rd $OUT/pmc_wr > $OUT/pmc_tcc.txt
 python3 profiles/show_pmc.py $OUT/pmc_sq > $OUT/pmc_sq.txt
 find $OUT/prof2 -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_two_lanes.csv \;
