@@ -523,6 +523,7 @@ int main(int argc, char **argv)
 		R3M(4, 2, 8, 2, 2, 2, 2, 0, "k3 three planes naf2 8+2+2 d2/2");
 		R3M(4, 4, 4, 3, 1, 2, 2, 0, "k3 three planes naf4 4+3+1 d2/2");
 		R3M(4, 2, 8, 3, 1, 2, 2, 1, "k3 three planes naf2 memory only");
+#ifdef S3_BENCH_SWEEPS   /* the shapes of the three-plane K = 3 kernel that were measured and not adopted (tools/README.md): -DS3_BENCH_SWEEPS, SWEEP3 / SWEEP4 / SWEEP5=1 */
 		if (getenv("SWEEP3")) {
 			R3M(4, 3, 8, 3, 1, 1, 1, 0, "k3 three planes naf3 8+3+1 d1/1");
 			R3M(4, 3, 8, 3, 1, 1, 2, 0, "k3 three planes naf3 8+3+1 d1/2");
@@ -533,6 +534,22 @@ int main(int argc, char **argv)
 			R3M(4, 2, 12, 3, 1, 1, 1, 0, "k3 three planes naf2 12+3+1 d1/1");
 			R3M(4, 3, 4, 3, 1, 2, 2, 0, "k3 three planes naf3 4+3+1 d2/2");
 			R3M(4, 4, 8, 3, 1, 1, 1, 0, "k3 three planes naf4 8+3+1 d1/1");
+		}
+		if (getenv("SWEEP5")) {
+			// NAF = 3 at two waves per SIMD (256 registers): 8 waves per workgroup
+			int badc = 0;
+			badc += check<4, 3, 6, 1, 1, 2, 2, 1, 2, 1, true>("three planes naf3 6+1+1", 2300, 777, 1, 8, 64);
+			badc += check<4, 3, 5, 2, 1, 2, 2, 1, 2, 1, true>("three planes naf3 5+2+1", 2300, 777, 1, 8, 64);
+			if (badc) return 1;
+			for (int rep = 0; rep < 2; rep++) {
+				R3M(4, 2, 8, 3, 1, 2, 2, 0, "k3 three planes naf2 8+3+1 d2/2");
+				R3M(4, 3, 6, 1, 1, 2, 2, 0, "k3 three planes naf3 6+1+1 d2/2");
+				R3M(4, 3, 6, 1, 1, 1, 2, 0, "k3 three planes naf3 6+1+1 d1/2");
+				R3M(4, 3, 5, 2, 1, 2, 2, 0, "k3 three planes naf3 5+2+1 d2/2");
+				R3M(4, 3, 5, 2, 1, 3, 2, 0, "k3 three planes naf3 5+2+1 d3/2");
+				R3M(4, 3, 6, 1, 1, 2, 2, 1, "k3 three planes naf3 6+1+1 memory only");
+			}
+			return 0;
 		}
 		if (getenv("SWEEP4")) {
 			int badc = 0;
@@ -551,6 +568,7 @@ int main(int argc, char **argv)
 			R3M(4, 2, 8, 2, 2, 3, 1, 0, "k3 three planes naf2 8+2+2 d3/1");
 			return 0;
 		}
+#endif
 		R3M(2, 4, 8, 3, 1, 1, 2, 0, "quant three planes naf4");
 		R3M(6, 3, 4, 2, 2, 2, 1, 0, "k5 three planes naf3 4+2+2");
 		R3M(12, 1, 4, 2, 2, 2, 1, 0, "k13 three planes naf1 4+2+2");
