@@ -397,7 +397,7 @@ def main():
             "note": "one lane (no SPA stage of the previous step running beside it), medians of 9 steps outside the timed region"},
         "stages": {
             "lists": {"avg_ms": round(ms_lists, 4), "kernel": "s3_lists_t3_kernel", "algorithmic_bytes": block * row_bytes,
-                      "frac_of_hbm_peak": round(block * row_bytes / (max(ms_lists, 1e-9) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "bound": "hbm",
+                      "frac_of_hbm_peak": round(block * row_bytes / (ms_lists * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms_lists > 0 else None, "bound": "hbm",
                       "note": "the two-plane form's pass over the rows (finds the missing genotypes and gathers their score vectors on the "
                               "spot: the rows are then read twice per step); 0 where the steps took the three-plane form -- up to 4 B "
                               "fragments (K = 3 binary) always, else from ~0.5 % missing genotypes -- which reads the rows once"},
