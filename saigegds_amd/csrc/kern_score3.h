@@ -74,20 +74,21 @@ __device__ __forceinline__ void s3_unpack_op(uint32_t w, uint32_t &w4, s3_v4i &v
 }
 // The three-plane form (MISS): beside the value and bit-1 planes the plane [code == 3] x s_t, multiplied into
 // EVERY value column: T3 (the sums over the missing samples) then comes out of the contraction itself and no
-// list of the missing genotypes is needed -- one read of the rows, at any missing rate.  16 operations per dword:
-// the nine above, then  t = w & (w >> 1)  (bit 2 s of t: code s is 3),  m4 = t >> 4,  and four masks -- bytes 1 / 4
-// at the even / odd positions, the position scales again.
+// list of the missing genotypes is needed -- one read of the rows, at any missing rate.  15 operations per dword:
+// the nine above, then  t = w >> 1,  t4 = w4 >> 1  and four three-input ANDs (v_bitop3_b32 on gfx950)
+// w & t & mask: bit 2 s of w & (w >> 1) says that code s is 3; bytes 1 / 4 at the even / odd positions, the
+// position scales again.  (Sixteen with t = w & (w >> 1) formed first: one two-input AND more than the fused form.)
+#define S3_UNPACK3_OPS 15
 template <int OP>
-__device__ __forceinline__ void s3_unpack3_op(uint32_t w, uint32_t &w4, uint32_t &t, uint32_t &m4, s3_v4i &val, s3_v4i &b1, s3_v4i &mis)
+__device__ __forceinline__ void s3_unpack3_op(uint32_t w, uint32_t &w4, uint32_t &t, uint32_t &t4, s3_v4i &val, s3_v4i &b1, s3_v4i &mis)
 {
 	if constexpr (OP < 9) s3_unpack_op<OP>(w, w4, val, b1);
 	else if constexpr (OP == 9) t = w >> 1;
-	else if constexpr (OP == 10) t = t & w;
-	else if constexpr (OP == 11) m4 = t >> 4;
-	else if constexpr (OP == 12) mis[0] = (int)(t & 0x01010101u);
-	else if constexpr (OP == 13) mis[1] = (int)(t & 0x04040404u);
-	else if constexpr (OP == 14) mis[2] = (int)(m4 & 0x01010101u);
-	else if constexpr (OP == 15) mis[3] = (int)(m4 & 0x04040404u);
+	else if constexpr (OP == 10) t4 = w4 >> 1;
+	else if constexpr (OP == 11) mis[0] = (int)(w & t & 0x01010101u);
+	else if constexpr (OP == 12) mis[1] = (int)(w & t & 0x04040404u);
+	else if constexpr (OP == 13) mis[2] = (int)(w4 & t4 & 0x01010101u);
+	else if constexpr (OP == 14) mis[3] = (int)(w4 & t4 & 0x04040404u);
 }
 
 // NBF: B fragments per tile (value fragments + the bit-1 fragment, the LAST one).  NAF: A fragments (16
@@ -471,14 +472,14 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 		}
 	};
 	// ---- the three-plane consumer (MISS): per dword step the MFMAs run (fragment, plane)-major -- B fragment b feeds the
-	// NAF value MFMAs, then the NAF missing-plane MFMAs, the bit-1 fragment its NAF -- and the 16 NAF operations that
+	// NAF value MFMAs, then the NAF missing-plane MFMAs, the bit-1 fragment its NAF -- and the 15 NAF operations that
 	// make the NEXT dword's planes (a second set of plane registers) are dealt out evenly behind them.
 	auto consume3 = [&]() {
 		static_assert(!MISS || (NCB == 1 && NBUF_ == 2), "the three-plane form has one column group and two chunk buffers");
 		constexpr int NBV = NBF - 1;                          // value fragments
 		constexpr int NVF = 2 * NBV + 1;                      // (fragment, plane) pairs of a dword step
 		constexpr int NM = NAF * NVF;                         // MFMAs per dword step
-		constexpr int NOPT = 16 * NAF;                        // operations per dword
+		constexpr int NOPT = S3_UNPACK3_OPS * NAF;            // operations per dword
 		constexpr int BCH = NBF <= 4 ? NBF : 2, NCH = (NBF + BCH - 1) / BCH;
 		const uint32_t bt_lds = smem_lds + (4 * kg * NCOL + r) * 16;
 		s3_v4i acc[NAF][NBF], accm[NAF][NBV > 0 ? NBV : 1];
@@ -516,7 +517,7 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 			s3_v4i val[2][NAF], b1[2][NAF], mis[2][NAF];
 			uint32_t w4[NAF], tt[NAF], m4[NAF];
 			s3_static_for<0, NOPT>([&](auto O) {
-				constexpr int o = decltype(O)::value, f = o / 16, op = o % 16;
+				constexpr int o = decltype(O)::value, f = o / S3_UNPACK3_OPS, op = o % S3_UNPACK3_OPS;
 				s3_unpack3_op<op>((uint32_t)aw[f][0], w4[f], tt[f], m4[f], val[0][f], b1[0][f], mis[0][f]);
 			});
 			__builtin_amdgcn_sched_barrier(0);
@@ -541,7 +542,7 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 					else acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1[vb][f], bf[ci % 2][j], acc[f][b], 0, 0, 0);
 					if constexpr (u < 3) {
 						s3_static_for<m * NOPT / NM, (m + 1) * NOPT / NM>([&](auto O) {
-							constexpr int o = decltype(O)::value, ff = o / 16, op = o % 16;
+							constexpr int o = decltype(O)::value, ff = o / S3_UNPACK3_OPS, op = o % S3_UNPACK3_OPS;
 							s3_unpack3_op<op>((uint32_t)aw[ff][u + 1], w4[ff], tt[ff], m4[ff], val[vn][ff], b1[vn][ff], mis[vn][ff]);
 						});
 					}
