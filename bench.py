@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0
 CLOCK_HZ = 2.4e9
 MFMA_CYCLES, MFMA_ISSUE, VALU_ISSUE = 16, 8, 4
 UNPACK_OPS = 9              # vector instructions per (16 variants x 16 samples) dword of score3_kernel (kern_score3.h)
-UNPACK_OPS_3 = 16           # ... of its three-plane form (s3_unpack3_op), which also has 2 nbf - 1 MFMAs per dword instead of nbf
+UNPACK_OPS_3 = 15           # ... of its three-plane form (s3_unpack3_op), which also has 2 nbf - 1 MFMAs per dword instead of nbf
 BOUND_NAME = {"hbm": "hbm", "mfma": "mfma", "valu_issue": "valu issue"}
 
 WORKLOADS = {

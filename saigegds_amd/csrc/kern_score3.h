@@ -122,7 +122,7 @@ __device__ __forceinline__ void s3_unpack3_op(uint32_t w, uint32_t &w4, uint32_t
 //   (RM = 2: timing experiment of the tool, wrong results.)
 // MISS: the three-plane form (s3_unpack3_op): a consumer wave keeps a second set of accumulators, the missing plane
 //   against the NBF - 1 value fragments; its slab is NAF x (2 NBF - 1) fragment slots, the missing plane's behind
-//   the NBF of the two-plane form.  NCB = 1, NBUF = 2 only.
+//   the NBF of the two-plane form.  NCB = 1 only.
 template <int NBF, int NAF, int NC, int NLA, int NLB, int DA, int DB, int ABL = 0, int NCB = 1, int NBUF_ = 2, int RM = 0, bool MISS = false>
 __global__ void __launch_bounds__(64 * (NC + NLA + NLB), (NC + NLA + NLB + 3) / 4)
 score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3Plan pl, int *__restrict__ out, unsigned long long *__restrict__ stamps)
@@ -475,7 +475,8 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 	// NAF value MFMAs, then the NAF missing-plane MFMAs, the bit-1 fragment its NAF -- and the 15 NAF operations that
 	// make the NEXT dword's planes (a second set of plane registers) are dealt out evenly behind them.
 	auto consume3 = [&]() {
-		static_assert(!MISS || (NCB == 1 && NBUF_ == 2), "the three-plane form has one column group and two chunk buffers");
+		static_assert(!MISS || NCB == 1, "the three-plane form has one column group");
+		constexpr int NBUF = NBUF_;                           // chunk buffers: the B reads run NBUF - 1 chunks ahead of their MFMAs
 		constexpr int NBV = NBF - 1;                          // value fragments
 		constexpr int NVF = 2 * NBV + 1;                      // (fragment, plane) pairs of a dword step
 		constexpr int NM = NAF * NVF;                         // MFMAs per dword step
@@ -500,18 +501,18 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 			const uint32_t b_addr = bt_lds + (uint32_t)(sb * TILE_BYTES);
 			s3_v4i aw[NAF];
 			s3_static_for<0, NAF>([&](auto F) { constexpr int f = decltype(F)::value; S3_DS_READ(aw[f], a_addr, f * AFS); });
-			s3_v4i bf[2][BCH];
+			s3_v4i bf[NBUF][BCH];
 			auto read_chunk = [&](auto CI) {
 				constexpr int ci = decltype(CI)::value, u = ci / NCH, b0 = (ci % NCH) * BCH;
 				s3_static_for<0, BCH>([&](auto J) {
 					constexpr int j = decltype(J)::value;
-					if constexpr (b0 + j < NBF) S3_DS_READ(bf[ci % 2][j], b_addr, u * NCOL * 16 + (b0 + j) * 256);
+					if constexpr (b0 + j < NBF) S3_DS_READ(bf[ci % NBUF][j], b_addr, u * NCOL * 16 + (b0 + j) * 256);
 				});
 			};
 			constexpr int nread_last = NBF - (NCH - 1) * BCH;
 			auto nreads = [](int c0, int c1) constexpr { int n = 0; for (int c = c0; c < c1 && c < 4 * NCH; c++) n += (c % NCH == NCH - 1) ? nread_last : BCH; return n; };
-			read_chunk(std::integral_constant<int, 0>());
-			S3_LGKM_WAIT(nreads(0, 1), aw[0]);
+			s3_static_for<0, NBUF - 1>([&](auto C) { if constexpr (decltype(C)::value < 4 * NCH) read_chunk(C); });
+			S3_LGKM_WAIT(nreads(0, NBUF - 1), aw[0]);
 #pragma unroll
 			for (int f = 1; f < NAF; f++) S3_TIE(aw[f]);
 			s3_v4i val[2][NAF], b1[2][NAF], mis[2][NAF];
@@ -530,16 +531,16 @@ score3_kernel(const uint8_t *__restrict__ A, const uint8_t *__restrict__ Fl, S3P
 					constexpr int ch = b / BCH, ci = u * NCH + ch, j = b % BCH;
 					if constexpr (f == 0 && plane != 1 && b % BCH == 0) {
 						// entering a chunk: start the next one, then wait for this one
-						if constexpr (ci + 1 < 4 * NCH) read_chunk(std::integral_constant<int, ci + 1>());
-						constexpr int inflight = nreads(ci + 1, ci + 2);
+						if constexpr (ci + NBUF - 1 < 4 * NCH) read_chunk(std::integral_constant<int, ci + NBUF - 1>());
+						constexpr int inflight = nreads(ci + 1, ci + NBUF);
 						constexpr int nb = (ch == NCH - 1) ? nread_last : BCH;
-						S3_LGKM_WAIT(inflight, bf[ci % 2][0]);
+						S3_LGKM_WAIT(inflight, bf[ci % NBUF][0]);
 #pragma unroll
-						for (int jj = 1; jj < nb; jj++) S3_TIE(bf[ci % 2][jj]);
+						for (int jj = 1; jj < nb; jj++) S3_TIE(bf[ci % NBUF][jj]);
 					}
-					if constexpr (plane == 0) acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(val[vb][f], bf[ci % 2][j], acc[f][b], 0, 0, 0);
-					else if constexpr (plane == 1) accm[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(mis[vb][f], bf[ci % 2][j], accm[f][b], 0, 0, 0);
-					else acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1[vb][f], bf[ci % 2][j], acc[f][b], 0, 0, 0);
+					if constexpr (plane == 0) acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(val[vb][f], bf[ci % NBUF][j], acc[f][b], 0, 0, 0);
+					else if constexpr (plane == 1) accm[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(mis[vb][f], bf[ci % NBUF][j], accm[f][b], 0, 0, 0);
+					else acc[f][b] = __builtin_amdgcn_mfma_i32_16x16x64_i8(b1[vb][f], bf[ci % NBUF][j], acc[f][b], 0, 0, 0);
 					if constexpr (u < 3) {
 						s3_static_for<m * NOPT / NM, (m + 1) * NOPT / NM>([&](auto O) {
 							constexpr int o = decltype(O)::value, ff = o / S3_UNPACK3_OPS, op = o % S3_UNPACK3_OPS;

@@ -523,6 +523,15 @@ int main(int argc, char **argv)
 		R3M(4, 2, 8, 2, 2, 2, 2, 0, "k3 three planes naf2 8+2+2 d2/2");
 		R3M(4, 4, 4, 3, 1, 2, 2, 0, "k3 three planes naf4 4+3+1 d2/2");
 		R3M(4, 2, 8, 3, 1, 2, 2, 1, "k3 three planes naf2 memory only");
+#define R3M3(NBF, NAF, NC, NLA, NLB, DA, DB, ABL, name) run<NBF, NAF, NC, NLA, NLB, DA, DB, ABL, 1, 3, 1, true>(name, Ar, Fl, ntile, M, 1, n_cu, out, oints, reps, nullptr, bpv)
+		if (getenv("NBUF3")) {
+			if (check<4, 2, 8, 3, 1, 2, 2, 1, 3, 1, true>("three planes, B reads two chunks ahead", 2300, 777, 1, 8, 64)) return 1;
+			for (int rep = 0; rep < 3; rep++) {
+				R3M(4, 2, 8, 3, 1, 2, 2, 0, "k3 three planes naf2 8+3+1 d2/2");
+				R3M3(4, 2, 8, 3, 1, 2, 2, 0, "k3 three planes naf2 8+3+1 d2/2 NBUF 3");
+			}
+			return 0;
+		}
 #ifdef S3_BENCH_SWEEPS   /* the shapes of the three-plane K = 3 kernel that were measured and not adopted (tools/README.md): -DS3_BENCH_SWEEPS, SWEEP3 / SWEEP4 / SWEEP5=1 */
 		if (getenv("SWEEP3")) {
 			R3M(4, 3, 8, 3, 1, 1, 1, 0, "k3 three planes naf3 8+3+1 d1/1");
