@@ -32,8 +32,12 @@ def gather_buffers(n_variants: int, device, group=None, dst: int = 0):
     if dist.get_rank(group) != dst:
         return None
     mmax = max(hi - lo for lo, hi in (shard_range(n_variants, r, world) for r in range(world)))
-    return ([torch.zeros((mmax, 8), dtype=torch.float64, device=device) for _ in range(world)],
-            [torch.zeros((mmax,), dtype=torch.uint8, device=device) for _ in range(world)])
+    # one allocation per table, the ranks' receive buffers are views of it: with equal shards the gathered table
+    # IS that allocation (no concatenation, nothing allocated when the gather runs)
+    big_o = torch.zeros((world * mmax, 8), dtype=torch.float64, device=device)
+    big_v = torch.zeros((world * mmax,), dtype=torch.uint8, device=device)
+    return ([big_o[r * mmax:(r + 1) * mmax] for r in range(world)],
+            [big_v[r * mmax:(r + 1) * mmax] for r in range(world)], big_o, big_v)
 
 
 def gather_table(out_local, valid_local, n_variants: int, group=None, dst: int = 0, recv=None):
@@ -63,6 +67,8 @@ def gather_table(out_local, valid_local, n_variants: int, group=None, dst: int =
     dist.gather(sv, recv[1] if rank == dst else None, dst=dst, group=group)
     if rank != dst:
         return None, None
+    if len(recv) == 4 and all(h - l == mmax for l, h in sizes):
+        return recv[2], recv[3]               # equal shards: the receive buffers are the table, in variant order
     out = torch.cat([g[:h - l] for g, (l, h) in zip(recv[0], sizes)], dim=0)
     valid = torch.cat([g[:h - l] for g, (l, h) in zip(recv[1], sizes)], dim=0)
     return out, valid
