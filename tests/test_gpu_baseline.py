@@ -91,6 +91,25 @@ def test_baseline_c3_exact_path_agrees():
     np.testing.assert_allclose(a[v][:, 3:7], b[v][:, 3:7], rtol=1e-11)
 
 
+def test_baseline_c3_both_kernel_forms_at_full_n():
+    """C3 at N = 430 000: the automatic choice for K = 3 is the three-plane form; forcing the two-plane form (list pass
+    with fourteen sample ranges, per-range sums added up by the epilogue) gives the same table -- the score columns
+    are the same exact integers either way."""
+    sm, sc, packed, bpv = _baseline_case(430_000, "binary", 0.01, 2000)
+    try:
+        a, va, ta = _scan_two_lanes(sc, packed, bpv, 1)
+        sc.set_option("three_plane", 0)
+        b, vb, tb = _scan_two_lanes(sc, packed, bpv, 1)
+    finally:
+        sc.close()
+    assert ta["three_plane"] == 1 and tb["three_plane"] == 0, (ta, tb)
+    assert tb["n_unlisted"] == 0 and ta["n_spa"] == tb["n_spa"]
+    assert np.array_equal(va, vb)
+    v = va.astype(bool)
+    assert np.array_equal(a[v][:, :3], b[v][:, :3])                         # AF, mac, num
+    np.testing.assert_allclose(a[v][:, 3:7], b[v][:, 3:7], rtol=1e-11)      # (the SPA lists are filled in another order)
+
+
 def test_baseline_c3_thirteen_covariates():
     """K = 13 at N = 430 000: eleven B fragments in one pass of the score kernel, 1024-sample segments and the
     8-wave form of the cumulant pass (420 segments), against the oracle."""
